@@ -1,0 +1,192 @@
+"""Generate the golden fixtures under tests/golden from the REFERENCE ITSELF.
+
+Runs only in the development container (it needs /root/reference); the GPU box
+never sees the reference, only the .npz files this writes.  The reference's
+``layers.py``, ``Trainer.py`` and ``Trainer_distilation.py`` are loaded by file
+path (never via sys.path: the reference ships a ``collections.py`` that would
+shadow the standard library), third-party imports that are not installed are
+replaced by empty modules, ``Tensor.cuda`` is neutralised because this container
+has no GPU, and ``torch.randn`` is pinned to the recorded tie-break noise while
+``compute_losses`` runs (Trainer.py:589 draws it from the CPU generator).
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.npz
+
+Every file holds: the inputs (fp32 values; the reference is fed their float64
+copies, as its data loader would produce), every intermediate the reference
+keeps in ``outputs``, the per-source photometric error maps, the loss values
+and the gradients with respect to the disparity and each pose matrix.
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/Python"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import mde_amd.synth as synth  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    layers = _load("layers", os.path.join(REF, "layers.py"))
+    for n in ["networks", "maskrcnn_benchmark", "maskrcnn_benchmark.config", "cv2", "eval_utils"]:
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["maskrcnn_benchmark.config"].cfg = None
+    sys.modules["eval_utils"].evaluate_depth = None
+    trainer = _load("ref_trainer", os.path.join(REF, "Trainer.py"))
+    distil = _load("ref_trainer_distil", os.path.join(REF, "Trainer_distilation.py"))
+    return layers, trainer, distil
+
+
+def make_trainer(cls, layers, B, H, W, c):
+    tr = object.__new__(cls)
+    tr.opt = types.SimpleNamespace(
+        scales=list(c["scales"]), frame_ids=list(c["frame_ids"]), v1_multiscale=False, height=H, width=W,
+        min_depth=0.1, max_depth=100.0, pose_model_type="shared",
+        disable_automasking=not c["automask"], predictive_mask=False,
+        avg_reprojection=c["avg_reprojection"], no_ssim=c["no_ssim"], disparity_smoothness=1e-3)
+    tr.num_scales = 1
+    tr.use_affinity = False
+    tr.val_mode = False
+    tr.epoch = 0
+    tr.backproject_depth = layers.BackprojectDepth(B, H, W)
+    tr.project_3d = layers.Project3D(B, H, W)
+    tr.ssim = layers.SSIM()
+    return tr
+
+
+CASES = [
+    # name, B, H, W, frame_ids, flags
+    dict(name="b2_24x80_automask", B=2, H=24, W=80, frame_ids=[0, -1, 1], automask=True),
+    dict(name="b2_24x80_noautomask", B=2, H=24, W=80, frame_ids=[0, -1, 1], automask=False),
+    dict(name="b1_13x37_automask", B=1, H=13, W=37, frame_ids=[0, -1, 1], automask=True, seed=5),
+    dict(name="b1_13x37_noautomask_avg", B=1, H=13, W=37, frame_ids=[0, -1, 1], automask=False,
+         avg_reprojection=True, seed=6),
+    dict(name="b2_24x80_automask_avg", B=2, H=24, W=80, frame_ids=[0, -1, 1], automask=True,
+         avg_reprojection=True, seed=7),
+    dict(name="b2_24x80_automask_nossim", B=2, H=24, W=80, frame_ids=[0, -1, 1], automask=True,
+         no_ssim=True, seed=8),
+    dict(name="b2_24x80_stereo", B=2, H=24, W=80, frame_ids=[0, -1, 1, "s"], automask=True, seed=9),
+    dict(name="b1_20x50_single_source", B=1, H=20, W=50, frame_ids=[0, 1], automask=False, seed=10),
+    dict(name="b1_20x50_single_source_automask", B=1, H=20, W=50, frame_ids=[0, 1], automask=True, seed=11),
+    dict(name="b2_24x80_scales4", B=2, H=24, W=80, frame_ids=[0, -1, 1], automask=True,
+         scales=[0, 1, 2, 3], seed=12),
+    dict(name="b2_24x80_large_motion", B=2, H=24, W=80, frame_ids=[0, -1, 1], automask=True,
+         pose_sigma=0.25, seed=13),
+    dict(name="b2_48x160_automask", B=2, H=48, W=160, frame_ids=[0, -1, 1], automask=True, seed=14),
+    dict(name="b3_16x33_sharp", B=3, H=16, W=33, frame_ids=[0, -1, 1], automask=True, seed=15, blur=1),
+    dict(name="b2_24x80_distil_scale09", B=2, H=24, W=80, frame_ids=[0, -1, 1], automask=True,
+         variant="distil", seed=16),
+    dict(name="b2_24x80_distil_single", B=2, H=24, W=80, frame_ids=[0, -1, 1], automask=True,
+         variant="distil_single", seed=17),
+]
+
+
+def run_case(c, layers, trainer, distil, out_dir):
+    c = dict(dict(avg_reprojection=False, no_ssim=False, scales=[0], seed=0, pose_sigma=0.01,
+                  variant="trainer", blur=5), **c)
+    B, H, W = c["B"], c["H"], c["W"]
+    fids = c["frame_ids"]
+    srcs = fids[1:]
+    data = synth.make_batch(B, H, W, fids, seed=c["seed"], pose_sigma=c["pose_sigma"], blur=c["blur"])
+    n_id = 1 if c["avg_reprojection"] else len(srcs)
+    noise = data["noise"][:, :n_id].contiguous()
+
+    cls = trainer.Trainer if c["variant"] == "trainer" else distil.Trainer
+    tr = make_trainer(cls, layers, B, H, W, c)
+
+    inputs = {"K": data["K"], "inv_K": data["inv_K"]}
+    for f in fids:
+        inputs[("image", f)] = data[("image", f)].double()
+    disp = data[("disp", 0)].clone().requires_grad_(True)
+    outputs = {("disp", 0): disp}
+    poses = {}
+    for f in srcs:
+        if f == "s":
+            poses[f] = data["stereo_T"].clone().requires_grad_(True)
+            inputs["stereo_T"] = poses[f]
+        else:
+            poses[f] = data[("cam_T_cam", f)].clone().requires_grad_(True)
+            outputs[("cam_T_cam", f)] = poses[f]
+
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: noise.clone()
+    try:
+        if c["variant"] == "trainer":
+            tr.generate_images_pred(inputs, outputs)
+            losses = tr.compute_losses(inputs, outputs)
+        elif c["variant"] == "distil":
+            teacher = {("disp", 0): data[("disp", 0)].clone()}
+            tr.generate_images_pred(inputs, outputs)
+            losses = tr.compute_losses(inputs, outputs, teacher, None, None, None)
+        else:
+            tr.generate_images_pred_single(inputs, outputs)
+            losses = tr.compute_losses_single(inputs, outputs)
+    finally:
+        torch.randn = real_randn
+    losses["loss"].backward()
+
+    rec = {"config": np.array(json.dumps({k: v for k, v in c.items()}))}
+    for f in fids:
+        rec["image_%s" % f] = data[("image", f)].numpy()
+    rec["disp"] = data[("disp", 0)].numpy()
+    rec["K"] = data["K"].numpy()
+    rec["inv_K"] = data["inv_K"].numpy()
+    rec["noise"] = noise.numpy()
+    rec["depth"] = outputs[("depth", 0)].detach().numpy()
+    target = inputs[("image", 0)]
+    with torch.no_grad():
+        pts = tr.backproject_depth(outputs[("depth", 0)], inputs["inv_K"])
+        rec["points"] = pts.numpy()
+    for f in srcs:
+        rec["T_%s" % f] = poses[f].detach().numpy()
+        rec["sample_%s" % f] = outputs[("sample", f)].detach().numpy()
+        rec["color_%s" % f] = outputs[("color", f)].detach().numpy()
+        with torch.no_grad():
+            rec["rp_%s" % f] = tr.compute_reprojection_loss(outputs[("color", f)], target).numpy()
+            rec["ssim_%s" % f] = tr.ssim(outputs[("color", f)], target).numpy()
+            rec["rp_identity_%s" % f] = tr.compute_reprojection_loss(inputs[("image", f)], target).numpy()
+        rec["grad_T_%s" % f] = poses[f].grad.numpy()
+    if c["automask"]:
+        rec["identity_selection"] = outputs["identity_selection"].numpy()
+    with torch.no_grad():
+        md = disp.mean(2, True).mean(3, True)
+        rec["smooth"] = layers.get_smooth_loss(disp / (md + 1e-7), target).numpy()
+    rec["loss"] = losses["loss"].detach().numpy()
+    for s in c["scales"]:
+        rec["loss_%d" % s] = losses["loss/%d" % s].detach().numpy()
+    rec["grad_disp"] = disp.grad.numpy()
+    path = os.path.join(out_dir, c["name"] + ".npz")
+    np.savez_compressed(path, **rec)
+    return path, float(rec["loss"]), float(np.abs(rec["grad_disp"]).sum())
+
+
+def main():
+    torch.set_num_threads(1)   # deterministic summation order on the CPU
+    layers, trainer, distil = load_reference()
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    for c in CASES:
+        path, loss, g = run_case(c, layers, trainer, distil, out_dir)
+        print("%-40s loss=%.10f |grad_disp|_1=%.6e  %6.1f KB" % (
+            os.path.basename(path), loss, g, os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,269 @@
+"""CPU oracle for the view-synthesis loss path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain PyTorch ops, what the reference computes on the
+path  disp -> depth -> back-projection -> projection -> bilinear warp ->
+SSIM/L1 photometric error -> auto-mask / per-pixel minimum -> edge-aware
+smoothness -> per-scale loss assembly.  Nothing in the shipped package imports
+it: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` do, and there it is the checker, never the thing measured as the
+product.
+
+Parity status: PINNED.  ``oracle/make_golden.py`` runs the reference's own
+``layers.py`` / ``Trainer.py`` / ``Trainer_distilation.py`` (loaded by file
+path in the development container) on seeded inputs and stores inputs, every
+intermediate, the loss and the gradients under ``tests/golden``;
+``tests/test_oracle_golden.py`` checks this restatement against those files.
+
+Reference lines followed (all under /root/reference/Python):
+  disp_to_depth ............ layers.py:16-25
+  back-projection .......... layers.py:139-174
+  projection ............... layers.py:177-202
+  warp ..................... Trainer.py:467 (F.grid_sample, border padding)
+  SSIM ..................... layers.py:229-262
+  photometric error ........ Trainer.py:481-495
+  auto-mask / minimum ...... Trainer.py:551-605
+  smoothness ............... layers.py:211-226, Trainer.py:609-614
+  loss assembly ............ Trainer.py:524-536,614-619
+  0.9 photometric scale .... Trainer_distilation.py:1232-1234
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+SSIM_C1 = 0.01 ** 2
+SSIM_C2 = 0.03 ** 2
+
+
+# --------------------------------------------------------------------------
+# configuration
+# --------------------------------------------------------------------------
+@dataclasses.dataclass
+class LossConfig:
+    """The option fields the path reads (options.py:40-72,105-135)."""
+    frame_ids: Sequence = (0, -1, 1)
+    scales: Sequence[int] = (0,)
+    height: int = 192
+    width: int = 640
+    min_depth: float = 0.1
+    max_depth: float = 100.0
+    automask: bool = True               # == not opt.disable_automasking
+    avg_reprojection: bool = False
+    no_ssim: bool = False
+    disparity_smoothness: float = 1e-3
+    v1_multiscale: bool = False
+    warp_scale: float = 1.0             # 0.9 in Trainer_distilation.compute_losses
+    num_scales: int = 1                 # Trainer.py:33 (divisor of the total)
+
+    @property
+    def sources(self) -> List:
+        return list(self.frame_ids[1:])
+
+
+# --------------------------------------------------------------------------
+# geometry
+# --------------------------------------------------------------------------
+def disp_to_depth(disp: torch.Tensor, min_depth: float, max_depth: float):
+    """layers.py:16-25 -- sigmoid disparity to (scaled disparity, depth)."""
+    lo = 1 / max_depth
+    hi = 1 / min_depth
+    scaled = lo + (hi - lo) * disp
+    return scaled, 1 / scaled
+
+
+def homogeneous_pixels(height: int, width: int, device=None) -> torch.Tensor:
+    """layers.py:149-159 -- [3, H*W] rows (x, y, 1), x fastest, float32."""
+    ys, xs = torch.meshgrid(
+        torch.arange(height, dtype=torch.float32, device=device),
+        torch.arange(width, dtype=torch.float32, device=device),
+        indexing="ij",
+    )
+    return torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(height * width, device=device)], 0)
+
+
+def backproject(depth: torch.Tensor, inv_K: torch.Tensor) -> torch.Tensor:
+    """layers.py:161-174 -- depth [B,1,H,W], inv_K [B,4,4] -> points [B,4,H*W]."""
+    b, _, h, w = depth.shape
+    pix = homogeneous_pixels(h, w, depth.device).unsqueeze(0).expand(b, 3, h * w)
+    rays = torch.matmul(inv_K[:, :3, :3], pix)
+    pts = depth.reshape(b, 1, -1) * rays
+    ones = torch.ones(b, 1, h * w, dtype=pts.dtype, device=pts.device)
+    return torch.cat([pts, ones], 1)
+
+
+def project(points: torch.Tensor, K: torch.Tensor, T: torch.Tensor,
+            height: int, width: int, eps: float = 1e-7) -> torch.Tensor:
+    """layers.py:188-202 -- points [B,4,HW] -> normalised grid [B,H,W,2]."""
+    b = points.shape[0]
+    P = torch.matmul(K, T)[:, :3, :]
+    cam = torch.matmul(P, points)
+    uv = cam[:, :2, :] / (cam[:, 2, :].unsqueeze(1) + eps)
+    uv = uv.reshape(b, 2, height, width).permute(0, 2, 3, 1)
+    scale = torch.tensor([width - 1, height - 1], dtype=uv.dtype, device=uv.device)
+    uv = uv / scale
+    return (uv - 0.5) * 2
+
+
+def warp(image: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
+    """Trainer.py:467 -- bilinear, border padding, align_corners=False; the grid is
+    promoted to the image dtype (float64 in the reference's data path)."""
+    return F.grid_sample(image, grid.to(image.dtype), mode="bilinear",
+                         padding_mode="border", align_corners=False)
+
+
+# --------------------------------------------------------------------------
+# photometric terms
+# --------------------------------------------------------------------------
+def ssim(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """layers.py:245-262 -- per-pixel (1-SSIM)/2 over a reflect-padded 3x3 window."""
+    x = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    y = F.pad(y, (1, 1, 1, 1), mode="reflect")
+
+    def box(t):
+        return F.avg_pool2d(t, 3, 1)
+
+    mu_x, mu_y = box(x), box(y)
+    var_x = box(x ** 2) - mu_x ** 2
+    var_y = box(y ** 2) - mu_y ** 2
+    cov = box(x * y) - mu_x * mu_y
+    num = (2 * mu_x * mu_y + SSIM_C1) * (2 * cov + SSIM_C2)
+    den = (mu_x ** 2 + mu_y ** 2 + SSIM_C1) * (var_x + var_y + SSIM_C2)
+    return torch.clamp((1 - num / den) / 2, 0, 1)
+
+
+def reprojection_error(pred: torch.Tensor, target: torch.Tensor, no_ssim: bool = False) -> torch.Tensor:
+    """Trainer.py:481-495 -- [B,1,H,W] photometric error."""
+    l1 = torch.abs(target - pred).mean(1, True)
+    if no_ssim:
+        return l1
+    return 0.85 * ssim(pred, target).mean(1, True) + 0.15 * l1
+
+
+def smoothness(disp: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
+    """layers.py:211-226 -- edge-aware first-order smoothness (0-dim)."""
+    ddx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
+    ddy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
+    idx = torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]).mean(1, keepdim=True)
+    idy = torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]).mean(1, keepdim=True)
+    # the reference multiplies in place, so the product keeps disp's dtype
+    ddx = (ddx * torch.exp(-idx)).to(disp.dtype)
+    ddy = (ddy * torch.exp(-idy)).to(disp.dtype)
+    return ddx.mean() + ddy.mean()
+
+
+# --------------------------------------------------------------------------
+# trainer-level steps
+# --------------------------------------------------------------------------
+def view_synthesis(inputs: Dict, outputs: Dict, cfg: LossConfig) -> None:
+    """Trainer.py:419-479 -- fills ("depth",0), ("sample",f), ("color",f)."""
+    for _scale in cfg.scales:
+        disp = outputs[("disp", 0)]
+        if not cfg.v1_multiscale:
+            disp = F.interpolate(disp, [cfg.height, cfg.width], mode="bilinear", align_corners=False)
+        _, depth = disp_to_depth(disp, cfg.min_depth, cfg.max_depth)
+        outputs[("depth", 0)] = depth
+        for f in cfg.sources:
+            T = inputs["stereo_T"] if f == "s" else outputs[("cam_T_cam", f)]
+            pts = backproject(depth, inputs["inv_K"])
+            grid = project(pts, inputs["K"], T, cfg.height, cfg.width)
+            outputs[("sample", f)] = grid
+            outputs[("color", f)] = warp(inputs[("image", f)], grid)
+            if cfg.automask:
+                outputs[("color_identity", f)] = inputs[("image", f)]
+
+
+def compute_losses(inputs: Dict, outputs: Dict, cfg: LossConfig,
+                   noise: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """Trainer.py:518-620 (affinity / predictive-mask branches excluded).
+
+    ``noise`` is the N(0,1) tie-break tensor of Trainer.py:589 ([B,S,H,W], or
+    [B,1,H,W] with avg_reprojection); drawn from torch.randn when omitted.
+    """
+    losses: Dict[str, torch.Tensor] = {}
+    total = 0
+    target = inputs[("image", 0)]
+    for scale in cfg.scales:
+        disp = outputs[("disp", 0)]
+        warped = torch.cat(
+            [reprojection_error(outputs[("color", f)], target, cfg.no_ssim) * cfg.warp_scale
+             if cfg.warp_scale != 1.0 else
+             reprojection_error(outputs[("color", f)], target, cfg.no_ssim)
+             for f in cfg.sources], 1)
+        if cfg.avg_reprojection:
+            warped = warped.mean(1, keepdim=True)
+
+        if cfg.automask:
+            ident = torch.cat(
+                [reprojection_error(inputs[("image", f)], target, cfg.no_ssim) for f in cfg.sources], 1)
+            if cfg.avg_reprojection:
+                ident = ident.mean(1, keepdim=True)
+            z = torch.randn(ident.shape) if noise is None else noise
+            ident = ident + z.to(ident.device) * 0.00001
+            combined = torch.cat((ident, warped), dim=1)
+        else:
+            combined = warped
+
+        if combined.shape[1] == 1:
+            chosen = combined
+        else:
+            chosen, idx = torch.min(combined, dim=1)
+        if cfg.automask:
+            outputs["identity_selection"] = (idx > ident.shape[1] - 1).float()
+
+        loss = chosen.mean()
+        mean_disp = disp.mean(2, True).mean(3, True)
+        loss = loss + cfg.disparity_smoothness * smoothness(disp / (mean_disp + 1e-7), target) / (2 ** scale)
+        total = total + loss
+        losses["loss/{}".format(scale)] = loss
+    losses["loss"] = total / cfg.num_scales
+    return losses
+
+
+def loss_forward_backward(inputs: Dict, outputs: Dict, cfg: LossConfig,
+                          noise: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """One pass of the whole path: view synthesis, losses, backward."""
+    view_synthesis(inputs, outputs, cfg)
+    losses = compute_losses(inputs, outputs, cfg, noise)
+    losses["loss"].backward()
+    return losses
+
+
+# --------------------------------------------------------------------------
+# pose helpers (layers.py:28-103) -- tiny [B,4,4] math used to build inputs
+# --------------------------------------------------------------------------
+def rotation_from_axisangle(vec: torch.Tensor) -> torch.Tensor:
+    """layers.py:64-103 -- vec [B,1,3] -> [B,4,4] (Rodrigues)."""
+    angle = torch.norm(vec, 2, 2, True)
+    axis = vec / (angle + 1e-7)
+    ca, sa = torch.cos(angle), torch.sin(angle)
+    C = 1 - ca
+    x, y, z = (axis[..., i].unsqueeze(1) for i in range(3))
+    # association order as in the reference: a*(b*C), so results are bit-identical
+    xy, yz, zx = x * (y * C), y * (z * C), z * (x * C)
+    rows = [
+        [x * (x * C) + ca, xy - z * sa, zx + y * sa],
+        [xy + z * sa, y * (y * C) + ca, yz - x * sa],
+        [zx - y * sa, yz + x * sa, z * (z * C) + ca],
+    ]
+    R = torch.zeros(vec.shape[0], 4, 4, dtype=vec.dtype, device=vec.device)
+    for i in range(3):
+        for j in range(3):
+            R[:, i, j] = rows[i][j].reshape(-1)
+    R[:, 3, 3] = 1
+    return R
+
+
+def transformation_from_parameters(axisangle: torch.Tensor, translation: torch.Tensor,
+                                   invert: bool = False) -> torch.Tensor:
+    """layers.py:28-61 -- (axisangle [B,1,3], translation [B,1,3]) -> [B,4,4]."""
+    R = rotation_from_axisangle(axisangle)
+    t = translation.clone()
+    if invert:
+        R = R.transpose(1, 2)
+        t = t * -1
+    Tm = torch.eye(4, dtype=t.dtype, device=t.device).repeat(t.shape[0], 1, 1)
+    Tm[:, :3, 3] = t.reshape(-1, 3)
+    return torch.matmul(R, Tm) if invert else torch.matmul(Tm, R)

@@ -1,0 +1,63 @@
+"""The CPU oracle against the fixtures produced by the reference itself.
+
+The oracle uses the same PyTorch primitives in the same order as the reference,
+so agreement is expected to the last bits of float64 / float32."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import build_dicts, case_names, load_case
+from oracle import vsl_oracle as O
+
+
+def make_cfg(cfg):
+    variant = cfg["variant"]
+    return O.LossConfig(
+        frame_ids=[("s" if f == "s" else int(f)) for f in cfg["frame_ids"]], scales=cfg["scales"],
+        height=cfg["H"], width=cfg["W"], automask=cfg["automask"], avg_reprojection=cfg["avg_reprojection"],
+        no_ssim=cfg["no_ssim"], warp_scale=0.9 if variant == "distil" else 1.0)
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_oracle_matches_reference_fixture(name):
+    torch.set_num_threads(1)
+    cfg, z = load_case(name)
+    ocfg = make_cfg(cfg)
+    inputs, outputs, disp, poses, noise, fids = build_dicts(cfg, z)
+    losses = O.loss_forward_backward(inputs, outputs, ocfg, noise)
+
+    np.testing.assert_array_equal(outputs[("depth", 0)].detach().numpy(), z["depth"])
+    for f in fids[1:]:
+        np.testing.assert_array_equal(outputs[("sample", f)].detach().numpy(), z["sample_%s" % f])
+        np.testing.assert_allclose(outputs[("color", f)].detach().numpy(), z["color_%s" % f], rtol=0, atol=1e-15)
+        with torch.no_grad():
+            rp = O.reprojection_error(outputs[("color", f)], inputs[("image", 0)], ocfg.no_ssim)
+        np.testing.assert_allclose(rp.numpy(), z["rp_%s" % f], rtol=1e-13, atol=1e-15)
+    if cfg["automask"]:
+        np.testing.assert_array_equal(outputs["identity_selection"].numpy(), z["identity_selection"])
+    np.testing.assert_allclose(losses["loss"].item(), float(z["loss"]), rtol=1e-13)
+    for s in cfg["scales"]:
+        np.testing.assert_allclose(losses["loss/%d" % s].item(), float(z["loss_%d" % s]), rtol=1e-13)
+    g = disp.grad.numpy()
+    assert np.linalg.norm(g - z["grad_disp"]) <= 1e-6 * np.linalg.norm(z["grad_disp"])
+    for f in fids[1:]:
+        gt, gr = poses[f].grad.numpy(), z["grad_T_%s" % f]
+        assert np.linalg.norm(gt - gr) <= 1e-6 * np.linalg.norm(gr)
+
+
+def test_backproject_points_match_fixture():
+    cfg, z = load_case("b2_24x80_automask")
+    depth = torch.from_numpy(z["depth"])
+    pts = O.backproject(depth, torch.from_numpy(z["inv_K"]))
+    np.testing.assert_array_equal(pts.numpy(), z["points"])
+
+
+def test_pose_helper_matches_synth():
+    import mde_amd.synth as synth
+    aa = torch.from_numpy(synth.normal(3, (4, 1, 3)).astype(np.float32)) * 0.1
+    tr = torch.from_numpy(synth.normal(4, (4, 1, 3)).astype(np.float32)) * 0.1
+    M = O.transformation_from_parameters(aa, tr)
+    M2 = synth._rodrigues(aa[:, 0].numpy(), tr[:, 0].numpy())
+    np.testing.assert_allclose(M.numpy(), M2, atol=1e-6)
+    Mi = O.transformation_from_parameters(aa, tr, invert=True)
+    np.testing.assert_allclose(torch.matmul(M, Mi).numpy(), np.tile(np.eye(4), (4, 1, 1)), atol=1e-6)
