@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused view-synthesis loss (forward + backward) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the hot path over one batch of synthetic KITTI-shaped
+input per rank: for every disparity head, vsl_loss_forward + vsl_loss_backward
+through the C-ABI (libvsloss.so).  Workload at N=1: 640x192, batch 12,
+frame_ids [0,-1,1], auto-masking on, 4 scales given as 4 DISTINCT full-resolution
+disparity heads (the reference's own loop would feed the same disparity 4 times;
+distinct heads are the harder, non-degenerate case).  For N>1 every rank runs the
+same per-rank workload on its own shard of the global batch (weak scaling, no
+data-path collective: the loss is per-image until its final mean).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+BYTES_PER_PX_FWD_BWD = {2: 84.0, 3: 108.0, 1: 60.0, 4: 132.0}   # 4*(1+3+3S) read twice + 4 written
+
+
+def build_inputs(B, H, W, fids, heads, dev, seed=0):
+    import mde_amd.synth as synth
+    data = synth.make_batch(B, H, W, fids, seed=seed, n_heads=heads)
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
+    return data, t
+
+
+class LossStep:
+    """Pre-bound C-ABI calls for one step (all heads), no per-step allocation."""
+
+    def __init__(self, t, B, H, W, fids, heads, dev, automask=True):
+        import mde_amd._abi as abi
+        self.abi = abi
+        self.dev = dev
+        srcs = fids[1:]
+        S = len(srcs)
+        self.descs, self.ws, self.losses, self.gdisp, self.gT, self.gT_ptrs = [], [], [], [], [], []
+        self.ident = torch.empty(B, H, W, device=dev)
+        for h in range(heads):
+            d = abi.LossDesc()
+            d.B, d.H, d.W, d.S = B, H, W, S
+            d.flags = abi.FLAG_AUTOMASK if automask else 0
+            d.min_depth, d.max_depth, d.eps = 0.1, 100.0, 1e-7
+            d.ssim_weight, d.l1_weight, d.warp_scale = 0.85, 0.15, 1.0
+            d.n_scales = 1
+            d.scale_weight[0] = 1e-3 / (2 ** h)
+            d.inv_num_scales = 1.0
+            d.disp = t[("disp", h)].data_ptr()
+            d.target = t[("image", fids[0])].data_ptr()
+            for s, f in enumerate(srcs):
+                d.source[s] = t[("image", f)].data_ptr()
+                d.T[s] = (t["stereo_T"] if f == "s" else t[("cam_T_cam", f)]).data_ptr()
+            d.K, d.inv_K = t["K"].data_ptr(), t["inv_K"].data_ptr()
+            d.noise = None          # in-kernel counter-based tie-break noise
+            d.seed = 1234 + h
+            n = abi.lib.vsl_loss_workspace_bytes(ctypes.byref(d))
+            self.descs.append(d)
+            self.ws.append(torch.empty(n, dtype=torch.uint8, device=dev))
+            self.losses.append(torch.zeros(abi.LOSS_SLOTS, device=dev))
+            self.gdisp.append(torch.empty(B, 1, H, W, device=dev))
+            gts = [torch.empty(B, 4, 4, device=dev) for _ in range(S)]
+            ptrs = (ctypes.c_void_p * abi.MAX_SOURCES)()
+            for s in range(S):
+                ptrs[s] = gts[s].data_ptr()
+            self.gT.append(gts)
+            self.gT_ptrs.append(ptrs)
+
+    def __call__(self, stream):
+        abi = self.abi
+        for h, d in enumerate(self.descs):
+            ws = self.ws[h]
+            abi.check(abi.lib.vsl_loss_forward(ctypes.byref(d), ws.data_ptr(), ws.numel(), self.losses[h].data_ptr(),
+                                               self.ident.data_ptr(), stream))
+            abi.check(abi.lib.vsl_loss_backward(ctypes.byref(d), ws.data_ptr(), ws.numel(), None,
+                                                self.gdisp[h].data_ptr(), self.gT_ptrs[h], stream))
+
+
+def cpu_baseline(data, B, H, W, fids, seconds=12.0):
+    """The CPU oracle (pure-PyTorch restatement of the reference path) on a bounded sample:
+    batch-2 slices of the same workload, one disparity head, all host threads."""
+    from oracle import vsl_oracle as O
+    nb = min(2, B)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    cfg = O.LossConfig(frame_ids=fids, height=H, width=W, automask=True)
+    inputs = {"K": data["K"][:nb], "inv_K": data["inv_K"][:nb]}
+    for f in fids:
+        inputs[("image", f)] = data[("image", f)][:nb].double()
+    noise = data["noise"][:nb]
+
+    def one():
+        disp = data[("disp", 0)][:nb].clone().requires_grad_(True)
+        outputs = {("disp", 0): disp}
+        for f in fids[1:]:
+            if f == "s":
+                inputs["stereo_T"] = data["stereo_T"][:nb].clone().requires_grad_(True)
+            else:
+                outputs[("cam_T_cam", f)] = data[("cam_T_cam", f)][:nb].clone().requires_grad_(True)
+        O.loss_forward_backward(inputs, outputs, cfg, noise)
+
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds or n >= 200:
+            break
+    return {"value": nb * n / el, "unit": "frames/s (one disparity head, fwd+bwd)", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": "%d passes of a batch-%d slice of the workload, 1 head, float64 images" % (n, nb)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--heads", type=int, default=4)
+    ap.add_argument("--stereo", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    B, H, W = args.batch, args.height, args.width
+    fids = [0, -1, 1, "s"] if args.stereo else [0, -1, 1]
+    S = len(fids) - 1
+    data, t = build_inputs(B, H, W, fids, args.heads, dev, seed=rank)
+    step = LossStep(t, B, H, W, fids, args.heads, dev)
+    stream_obj = torch.cuda.current_stream(dev)
+    stream = stream_obj.cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(stream)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream_obj)
+    for _ in range(args.steps):
+        step(stream)
+    ev1.record(stream_obj)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist:
+        wt = torch.tensor([wall], device=dev, dtype=torch.float64)
+        td.all_reduce(wt, op=td.ReduceOp.MAX)
+        wall = wt.item()
+    gpu_ms = ev0.elapsed_time(ev1)
+
+    # per-kernel timing of the dominant kernel (fused tile kernel) with events around it alone
+    import mde_amd._abi as abi
+    d0, ws0 = step.descs[0], step.ws[0]
+    reps = 50
+    torch.cuda.synchronize(dev)
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record(stream_obj)
+    for _ in range(reps):
+        abi.lib.vsl_loss_forward(ctypes.byref(d0), ws0.data_ptr(), ws0.numel(), step.losses[0].data_ptr(),
+                                 step.ident.data_ptr(), stream)
+    k1.record(stream_obj)
+    torch.cuda.synchronize(dev)
+    fwd_ms = k0.elapsed_time(k1) / reps
+    k0.record(stream_obj)
+    for _ in range(reps):
+        abi.lib.vsl_loss_backward(ctypes.byref(d0), ws0.data_ptr(), ws0.numel(), None, step.gdisp[0].data_ptr(),
+                                  step.gT_ptrs[0], stream)
+    k1.record(stream_obj)
+    torch.cuda.synchronize(dev)
+    bwd_ms = k0.elapsed_time(k1) / reps
+
+    if rank == 0:
+        frames = B * world * args.steps
+        ms_per_step = wall * 1e3 / args.steps
+        alg_bytes = BYTES_PER_PX_FWD_BWD[S] * B * H * W            # one head, forward+backward
+        head_ms = fwd_ms + bwd_ms
+        achieved = alg_bytes / (head_ms * 1e-3) / 1e9
+        out = {
+            "metric": "training frames/s (loss fwd+bwd) at 640x192 b12",
+            "value": frames / wall, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d b%d per GPU, frame_ids %s, automask, %d distinct full-res disparity heads "
+                                   "(scales 0..%d), fused fwd+bwd through the C-ABI" % (W, H, B, fids, args.heads, args.heads - 1),
+                       "global_batch": B * world, "heads": args.heads},
+            "gpu_ms_per_step": gpu_ms / args.steps,
+            "frames_per_s_per_head": frames * args.heads / wall,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "vsl_fused_kernel (+finalize, grad) per head",
+                         "algorithmic_bytes": alg_bytes, "ms": head_ms, "fwd_ms": fwd_ms, "bwd_ms": bwd_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(data, B, H, W, fids)
+        print(json.dumps(out))
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

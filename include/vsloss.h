@@ -1,0 +1,121 @@
+/*
+ * vsloss.h -- C ABI of libvsloss.so: the Monodepth2-style view-synthesis loss
+ * (forward + backward) as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (sharjeel1999/Monocular-depth-estimation) has no FFI for this
+ * path: it is eager PyTorch.  Each entry point below therefore names the
+ * reference Python code it replaces; a maintainer binds these symbols with
+ * ctypes (Python trainers) or links them from libtorch C++ (cpp/main_trainer.hpp,
+ * where process_batch ends at line 142 before any loss exists).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - images / disparities are float32, NCHW-contiguous; matrices are row-major
+ *     [B,4,4] float32;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     all work is enqueued on it, nothing synchronises the host;
+ *   - functions allocate nothing: the caller owns a workspace of
+ *     vsl_loss_workspace_bytes() bytes (256-byte aligned) that must stay alive
+ *     and untouched between vsl_loss_forward and vsl_loss_backward;
+ *   - return value 0 = success, negative = error (see VSL_ERR_*); the message of
+ *     the calling thread's last error is returned by vsl_last_error_string().
+ */
+#ifndef VSLOSS_H
+#define VSLOSS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSL_MAX_SOURCES 4
+#define VSL_MAX_SCALES 8
+
+/* flag bits of vsl_loss_desc.flags (Python/options.py:105-135) */
+#define VSL_FLAG_AUTOMASK 1u         /* == not opt.disable_automasking  (Trainer.py:553,587) */
+#define VSL_FLAG_AVG_REPROJECTION 2u /* opt.avg_reprojection            (Trainer.py:562,582) */
+#define VSL_FLAG_NO_SSIM 4u          /* opt.no_ssim                     (Trainer.py:489)     */
+#define VSL_FLAG_NO_GRAD 8u          /* forward only: gradients are not prepared             */
+
+#define VSL_OK 0
+#define VSL_ERR_INVALID_ARGUMENT (-1)
+#define VSL_ERR_WORKSPACE_TOO_SMALL (-2)
+#define VSL_ERR_LAUNCH_FAILED (-3)
+
+/* slots of the `losses` output of vsl_loss_forward */
+#define VSL_LOSS_TOTAL 0  /* losses["loss"]            (Trainer.py:618-619) */
+#define VSL_LOSS_PHOTO 1  /* to_optimise.mean()        (Trainer.py:605)     */
+#define VSL_LOSS_SMOOTH 2 /* get_smooth_loss(norm_disp, color) (Trainer.py:612) */
+#define VSL_LOSS_SCALE0 3 /* losses["loss/{scale}"] for the i-th entry of scale_weight (Trainer.py:616) */
+#define VSL_LOSS_SLOTS (3 + VSL_MAX_SCALES)
+
+/*
+ * One fused evaluation of
+ *   Trainer.generate_images_pred  (Python/Trainer.py:419-479)  +
+ *   Trainer.compute_losses        (Python/Trainer.py:518-620)
+ * for ONE disparity tensor.  The reference reads outputs[("disp",0)] in every
+ * iteration of its `for scale in self.opt.scales` loop, so all its scales share
+ * the photometric term; that is expressed here by n_scales / scale_weight.
+ */
+typedef struct vsl_loss_desc {
+  int32_t B, H, W; /* batch, height, width (H >= 2, W >= 2)                     */
+  int32_t S;       /* number of source frames, 1..VSL_MAX_SOURCES (frame_ids[1:]) */
+  uint32_t flags;  /* VSL_FLAG_*                                                 */
+
+  float min_depth, max_depth; /* disp_to_depth (layers.py:16-25); defaults 0.1, 100  */
+  float eps;                  /* Project3D eps (layers.py:180); default 1e-7          */
+  float ssim_weight;          /* 0.85 (Trainer.py:493)                                */
+  float l1_weight;            /* 0.15 (Trainer.py:493)                                */
+  float warp_scale;           /* 1.0, or 0.9 as in Trainer_distilation.py:1234        */
+
+  int32_t n_scales;                     /* len(opt.scales), 1..VSL_MAX_SCALES         */
+  float scale_weight[VSL_MAX_SCALES];   /* disparity_smoothness / 2**scale (Trainer.py:614) */
+  float inv_num_scales;                 /* 1 / self.num_scales (Trainer.py:33,618) = 1 */
+
+  const float* disp;                     /* [B,1,H,W] sigmoid disparity, outputs[("disp",0)] */
+  const float* target;                   /* [B,3,H,W] inputs[("image",0)]                    */
+  const float* source[VSL_MAX_SOURCES];  /* [B,3,H,W] inputs[("image",f)], f in frame_ids[1:] */
+  const float* K;                        /* [B,4,4] inputs["K"]                              */
+  const float* inv_K;                    /* [B,4,4] inputs["inv_K"]                          */
+  const float* T[VSL_MAX_SOURCES];       /* [B,4,4] outputs[("cam_T_cam",f)] or inputs["stereo_T"] */
+  const float* noise;                    /* [B,S,H,W] ([B,1,H,W] with AVG_REPROJECTION) N(0,1) tie-break
+                                            noise of Trainer.py:589, or NULL: the kernel then draws it from
+                                            a counter-based generator keyed by `seed`               */
+  uint64_t seed;
+} vsl_loss_desc;
+
+/* Bytes of workspace vsl_loss_forward / vsl_loss_backward need for this shape. */
+size_t vsl_loss_workspace_bytes(const vsl_loss_desc* desc);
+
+/*
+ * Forward: fills losses[VSL_LOSS_SLOTS] (device floats) and, when not NULL,
+ * identity_selection [B,H,W] (outputs["identity_selection"], Trainer.py:601-603;
+ * only written with VSL_FLAG_AUTOMASK).  Unless VSL_FLAG_NO_GRAD is set it also
+ * leaves in the workspace everything vsl_loss_backward needs.
+ */
+int vsl_loss_forward(const vsl_loss_desc* desc, void* workspace, size_t workspace_bytes, float* losses,
+                     float* identity_selection, void* stream);
+
+/*
+ * Backward (the autograd pass that `.backward()` runs over Trainer.py:419-620):
+ * grad_disp [B,1,H,W]; grad_T[s] [B,4,4] for each source (entries, or the array
+ * itself, may be NULL to skip).  grad_losses is a device array of VSL_LOSS_SLOTS
+ * floats holding d(objective)/d(losses[i]) for every slot of the forward output
+ * (normally 1 in VSL_LOSS_TOTAL and 0 elsewhere), or NULL for exactly that
+ * default.  `grad_T` is a HOST array of S device pointers.
+ */
+int vsl_loss_backward(const vsl_loss_desc* desc, const void* workspace, size_t workspace_bytes,
+                      const float* grad_losses, float* grad_disp, float* const* grad_T, void* stream);
+
+/* Message of the last error raised on the calling thread ("" if none). */
+const char* vsl_last_error_string(void);
+
+/* Library version, e.g. 100 for 0.1.0. */
+int vsl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSLOSS_H */

@@ -1,0 +1,71 @@
+"""ctypes binding of libvsloss.so -- the C-ABI boundary declared in include/vsloss.h.
+
+The library is hand-written HIP for gfx950 and there is no other implementation
+behind these functions: if the shared object is missing or fails to load, the
+import raises, it never falls back to a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvsloss.so")
+
+MAX_SOURCES = 4
+MAX_SCALES = 8
+FLAG_AUTOMASK, FLAG_AVG_REPROJECTION, FLAG_NO_SSIM, FLAG_NO_GRAD = 1, 2, 4, 8
+LOSS_TOTAL, LOSS_PHOTO, LOSS_SMOOTH, LOSS_SCALE0 = 0, 1, 2, 3
+LOSS_SLOTS = 3 + MAX_SCALES
+
+EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward",
+           "vsl_last_error_string", "vsl_version")
+
+
+class LossDesc(ctypes.Structure):
+    """Mirror of ``vsl_loss_desc`` (include/vsloss.h)."""
+    _fields_ = [
+        ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("S", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("min_depth", ctypes.c_float), ("max_depth", ctypes.c_float), ("eps", ctypes.c_float),
+        ("ssim_weight", ctypes.c_float), ("l1_weight", ctypes.c_float), ("warp_scale", ctypes.c_float),
+        ("n_scales", ctypes.c_int32), ("scale_weight", ctypes.c_float * MAX_SCALES),
+        ("inv_num_scales", ctypes.c_float),
+        ("disp", ctypes.c_void_p), ("target", ctypes.c_void_p), ("source", ctypes.c_void_p * MAX_SOURCES),
+        ("K", ctypes.c_void_p), ("inv_K", ctypes.c_void_p), ("T", ctypes.c_void_p * MAX_SOURCES),
+        ("noise", ctypes.c_void_p), ("seed", ctypes.c_uint64),
+    ]
+
+
+class VslError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libvsloss.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950) -- there is no fallback implementation")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.vsl_loss_workspace_bytes.restype = ctypes.c_size_t
+    lib.vsl_loss_workspace_bytes.argtypes = [ctypes.POINTER(LossDesc)]
+    lib.vsl_loss_forward.restype = ctypes.c_int
+    lib.vsl_loss_forward.argtypes = [ctypes.POINTER(LossDesc), ctypes.c_void_p, ctypes.c_size_t,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.vsl_loss_backward.restype = ctypes.c_int
+    lib.vsl_loss_backward.argtypes = [ctypes.POINTER(LossDesc), ctypes.c_void_p, ctypes.c_size_t,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.c_void_p]
+    lib.vsl_last_error_string.restype = ctypes.c_char_p
+    lib.vsl_last_error_string.argtypes = []
+    lib.vsl_version.restype = ctypes.c_int
+    lib.vsl_version.argtypes = []
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise VslError("libvsloss error %d: %s" % (rc, lib.vsl_last_error_string().decode()))

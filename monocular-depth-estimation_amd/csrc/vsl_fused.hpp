@@ -1,0 +1,764 @@
+// Fused view-synthesis-loss tile program (forward + gradient in one pass).
+//
+// One workgroup owns a TW x TH tile of target pixels of one batch element and
+// runs four barrier-separated phases over LDS planes:
+//
+//   phase 1  every position of the tile grown by 2 (region R2): disparity ->
+//            depth -> back-projection -> projection -> bilinear sample of each
+//            source; target / identity-source / warped values go to LDS, the
+//            tap derivatives of the thread's own two interior pixels stay in
+//            registers.                           (layers.py:16-25,161-202, Trainer.py:467)
+//   phase 2a identity-reprojection error of every source on the tile grown by
+//            1 (region R1), plus tie-break noise, running minimum.   (Trainer.py:553-566,587-590)
+//   phase 2b photometric error of every warped source on R1 (3x3 SSIM with
+//            reflection padding + L1), running minimum / argmin, SSIM gradient
+//            coefficients of the winner into LDS.      (layers.py:245-262, Trainer.py:481-495,592-605)
+//   phase 3  interior pixels: 3x3 gather of the coefficients -> dL/dwarped ->
+//            bilinear/projection chain -> dL/ddisp and the 3x4 projection
+//            gradient; edge-aware smoothness terms.    (layers.py:211-226, Trainer.py:609-614)
+//   phase 4  deterministic block reduction of the partial sums.
+//
+// The phases are plain functions of (thread id, LDS base, per-thread state) so
+// that the same source also compiles as an ordinary C++ program that runs the
+// threads of a block one after the other (used by the CPU test build for
+// address-sanitizer and parity checks; it is not part of the shipped library).
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define VSL_DEV __device__ __forceinline__
+#define VSL_FMUL(a, b) __fmul_rn((a), (b))
+#define VSL_FADD(a, b) __fadd_rn((a), (b))
+#define VSL_FSUB(a, b) __fsub_rn((a), (b))
+#define VSL_FDIV(a, b) __fdiv_rn((a), (b))
+#define VSL_EXP(x) __expf(x)
+#else
+// host build: compile with -ffp-contract=off so that a*b+c is never fused
+#define VSL_DEV inline
+#define VSL_FMUL(a, b) ((a) * (b))
+#define VSL_FADD(a, b) ((a) + (b))
+#define VSL_FSUB(a, b) ((a) - (b))
+#define VSL_FDIV(a, b) ((a) / (b))
+#define VSL_EXP(x) expf(x)
+#endif
+
+namespace vsl {
+
+constexpr int kMaxSrc = 4;
+constexpr float kC1 = 0.01f * 0.01f;
+constexpr float kC2 = 0.03f * 0.03f;
+
+// number of per-block partial sums: photo, sum(disp), Sx, Sy, then 12 per source
+constexpr int num_partials(int S) { return 4 + 12 * S; }
+constexpr int kPartStride = 4 + 12 * kMaxSrc;  // stride of one block's record in the workspace
+
+struct KParams {
+  int B, H, W, S;
+  int automask, no_ssim;
+  float a_disp, c_disp;  // scaled = a + c * disp
+  float eps;
+  float cst_ssim;  // weight of (sum A + x sum B + y sum G) in dL/dwarped
+  float cst_l1;    // weight of -sign(y - x) in dL/dwarped for the selected source
+  float ssim_w3, l1_w3;  // ssim_weight/3, l1_weight/3 (channel means folded in)
+  float warp_scale;
+  float inv_nx, inv_ny;  // 1/(B*H*(W-1)), 1/(B*(H-1)*W)
+  const float* disp;
+  const float* tgt;
+  const float* src[kMaxSrc];
+  const float* K;
+  const float* invK;
+  const float* T[kMaxSrc];
+  const float* noise;
+  unsigned long long seed;
+  float* gphoto;     // [B,H,W] d(photo_w * photo)/d disp
+  float* gedge;      // [B,H,W] edge part of the smoothness gradient (before the per-image factors)
+  float* ident_sel;  // [B,H,W] or null
+  float* partials;   // [blocks][kPartStride]
+  unsigned int* counter;  // arrival counter of the finalize kernel, cleared here
+  int want_grad;
+};
+
+// ----------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------
+VSL_DEV int reflect_clamp(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  if (i < 0) i = 0;
+  if (i > n - 1) i = n - 1;
+  return i;
+}
+
+VSL_DEV float fast_rcp(float x) {
+#if defined(__HIPCC__)
+  float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.0f), r, r);  // one Newton step: ~0.5 ulp
+#else
+  return 1.0f / x;
+#endif
+}
+
+VSL_DEV float sgn(float v) { return (float)(v > 0.0f) - (float)(v < 0.0f); }
+
+// splitmix64-style hash -> N(0,1); used when the caller passes no noise tensor
+VSL_DEV float hash_normal(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  float u1 = ((float)((z >> 40) & 0xFFFFFF) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+  float u2 = (float)((z >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
+}
+
+// Projection matrix P = (K @ T)[:3,:] with separate multiply and add roundings
+// (what a batched 4x4 matmul on the CPU produces), layers.py:189.
+VSL_DEV float proj_entry(const float* K, const float* T, int i, int j) {
+  float acc = VSL_FMUL(K[i * 4 + 0], T[0 * 4 + j]);
+  for (int q = 1; q < 4; ++q) acc = VSL_FADD(acc, VSL_FMUL(K[i * 4 + q], T[q * 4 + j]));
+  return acc;
+}
+
+struct alignas(8) float2v {
+  float x, y;
+};
+
+struct Taps {
+  int i0, i1;
+  float t;
+  float live;  // 1 where d(sample)/d(coordinate) passes (0 < coordinate < n-1)
+};
+
+// grid_sample(align_corners=False, padding_mode="border") along one axis:
+// unnormalise, clip, floor and fraction in float64 from the float32 grid value.
+VSL_DEV Taps axis_taps(float g, int n) {
+  double c = (((double)g + 1.0) * (double)n - 1.0) * 0.5;
+  Taps tp;
+  tp.live = (c > 0.0 && c < (double)(n - 1)) ? 1.0f : 0.0f;
+  double cc = fmin(fmax(c, 0.0), (double)(n - 1));
+  double f = floor(cc);
+  tp.t = (float)(cc - f);
+  int i0 = (int)f;
+  if (i0 < 0) i0 = 0;
+  if (i0 > n - 1) i0 = n - 1;
+  tp.i0 = i0;
+  tp.i1 = (i0 + 1 > n - 1) ? n - 1 : i0 + 1;
+  return tp;
+}
+
+struct Chain {  // what phase 3 needs from phase 1 for one (pixel, source)
+  float dpx[3], dpy[3];  // d warped_c / d ix, d iy (already zero outside the clip range)
+  float u, v, inv_den;
+};
+
+template <int S>
+struct ThreadState {
+  Chain ch[2][S];
+  float part[num_partials(S)];
+};
+
+// ----------------------------------------------------------------------------
+// tile program
+// ----------------------------------------------------------------------------
+template <int TW, int TH, int NT, int S, bool AVG>
+struct Fused {
+  static_assert(TW % 2 == 0, "tile width must be even");
+  static constexpr int R2W = TW + 4, R2H = TH + 4, P2 = R2W * R2H;
+  static constexpr int R1W = TW + 2, R1H = TH + 2, P1 = R1W * R1H;
+  static constexpr int NPAIR1 = (R1W / 2) * R1H;
+  static constexpr int NPAIR0 = (TW / 2) * TH;
+  static constexpr int NHALO = P2 - TW * TH;
+  static constexpr int NSET = AVG ? S : 1;
+  static constexpr int NPART = num_partials(S);
+  static_assert(NPAIR1 <= NT && NPAIR0 <= NT, "not enough threads for the tile");
+  static_assert(P2 % 2 == 0 && P1 % 2 == 0, "planes must keep 8-byte alignment");
+
+  // LDS layout in floats
+  static constexpr int OFF_MAT = 0;                      // 12*S projection entries + 9 inv_K entries
+  static constexpr int MAT_FLOATS = ((12 * S + 9 + 3) / 4) * 4;
+  static constexpr int OFF_TGT = OFF_MAT + MAT_FLOATS;   // 3 planes over R2
+  static constexpr int OFF_WRP = OFF_TGT + 3 * P2;       // S*3 planes over R2
+  static constexpr int OFF_DSP = OFF_WRP + S * 3 * P2;   // 1 plane over R2
+  static constexpr int OFF_U = OFF_DSP + P2;             // union: identity sources | coefficients
+  static constexpr int U_IDENT = S * 3 * P2;
+  static constexpr int U_COEF = (NSET * 9 + 1) * P1;
+  static constexpr int U_SIZE = U_IDENT > U_COEF ? U_IDENT : U_COEF;
+  static constexpr int RED_PITCH = NT + 1;
+  static constexpr int RED_FLOATS = NPART * RED_PITCH;
+  static constexpr int LDS_MAIN = OFF_U + U_SIZE;
+  static constexpr int RED_TOTAL = RED_FLOATS + NPART * 8;
+  static constexpr int LDS_FLOATS = LDS_MAIN > RED_TOTAL ? LDS_MAIN : RED_TOTAL;
+
+  struct Block {
+    int b, x0, y0;
+  };
+
+  // ---- phase 0: projection matrices into LDS ---------------------------------
+  static VSL_DEV void phase0(const KParams& kp, const Block& bk, int tid, float* lds) {
+    if (tid == 0 && bk.b == 0 && bk.x0 == 0 && bk.y0 == 0 && kp.counter) *kp.counter = 0u;
+    if (tid < 12 * S) {
+      int s = tid / 12, e = tid % 12;
+      lds[OFF_MAT + tid] = proj_entry(kp.K + 16 * bk.b, kp.T[s] + 16 * bk.b, e / 4, e % 4);
+    } else if (tid < 12 * S + 9) {
+      int e = tid - 12 * S;
+      lds[OFF_MAT + tid] = kp.invK[16 * bk.b + (e / 3) * 4 + (e % 3)];
+    }
+  }
+
+  // ---- phase 1: one R2 position --------------------------------------------
+  static VSL_DEV void warp_position(const KParams& kp, const Block& bk, int ry, int rx, float* lds, Chain* chain) {
+    const int H = kp.H, W = kp.W;
+    const int py = reflect_clamp(bk.y0 - 2 + ry, H);
+    const int px = reflect_clamp(bk.x0 - 2 + rx, W);
+    const int p2 = ry * R2W + rx;
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
+    const size_t img0 = (size_t)bk.b * 3 * HW;
+
+    const float d = kp.disp[(size_t)bk.b * HW + pix];
+    lds[OFF_DSP + p2] = d;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lds[OFF_TGT + c * P2 + p2] = kp.tgt[img0 + c * HW + pix];
+    if (kp.automask) {
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lds[OFF_U + (s * 3 + c) * P2 + p2] = kp.src[s][img0 + c * HW + pix];
+    }
+
+    // disp_to_depth and the back-projected ray, layers.py:21-25,163-169
+    const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
+    const float D = VSL_FDIV(1.0f, sd);
+    const float fx = (float)px, fy = (float)py;
+    const float* ik = lds + OFF_MAT + 12 * S;
+    float X[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float r = VSL_FMUL(ik[i * 3 + 0], fx);
+      r = fmaf(ik[i * 3 + 1], fy, r);
+      r = fmaf(ik[i * 3 + 2], 1.0f, r);
+      X[i] = VSL_FMUL(D, r);
+    }
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float* P = lds + OFF_MAT + 12 * s;
+      float cam[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float a = VSL_FMUL(P[i * 4 + 0], X[0]);
+        a = fmaf(P[i * 4 + 1], X[1], a);
+        a = fmaf(P[i * 4 + 2], X[2], a);
+        a = fmaf(P[i * 4 + 3], 1.0f, a);
+        cam[i] = a;
+      }
+      // layers.py:196-201
+      const float den = VSL_FADD(cam[2], kp.eps);
+      const float u = VSL_FDIV(cam[0], den), v = VSL_FDIV(cam[1], den);
+      const float gx = VSL_FMUL(VSL_FSUB(VSL_FDIV(u, wm1), 0.5f), 2.0f);
+      const float gy = VSL_FMUL(VSL_FSUB(VSL_FDIV(v, hm1), 0.5f), 2.0f);
+      const Taps tx = axis_taps(gx, W), ty = axis_taps(gy, H);
+      const float* sp = kp.src[s] + img0;
+      const size_t o00 = (size_t)ty.i0 * W + tx.i0, o01 = (size_t)ty.i0 * W + tx.i1;
+      const size_t o10 = (size_t)ty.i1 * W + tx.i0, o11 = (size_t)ty.i1 * W + tx.i1;
+      const float w00 = (1.0f - tx.t) * (1.0f - ty.t), w01 = tx.t * (1.0f - ty.t);
+      const float w10 = (1.0f - tx.t) * ty.t, w11 = tx.t * ty.t;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v00 = sp[c * HW + o00], v01 = sp[c * HW + o01];
+        const float v10 = sp[c * HW + o10], v11 = sp[c * HW + o11];
+        lds[OFF_WRP + (s * 3 + c) * P2 + p2] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+        if (chain) {
+          chain[s].dpx[c] = tx.live * ((1.0f - ty.t) * (v01 - v00) + ty.t * (v11 - v10));
+          chain[s].dpy[c] = ty.live * ((1.0f - tx.t) * (v10 - v00) + tx.t * (v11 - v01));
+        }
+      }
+      if (chain) {
+        chain[s].u = u;
+        chain[s].v = v;
+        chain[s].inv_den = VSL_FDIV(1.0f, den);
+      }
+    }
+  }
+
+  static VSL_DEV void phase1(const KParams& kp, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
+    for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
+    if (tid < NPAIR0) {
+      const int iy = tid / (TW / 2), ip = tid % (TW / 2);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) warp_position(kp, bk, 2 + iy, 2 + 2 * ip + k, lds, st.ch[k]);
+    }
+    // halo ring of R2: the threads without an interior pair take three positions
+    // each, the remainder goes to the first threads
+    constexpr int EXTRA = NT - NPAIR0;
+    constexpr int NH_A = (3 * EXTRA < NHALO) ? 3 * EXTRA : NHALO;
+    if (tid >= NPAIR0) {
+      for (int h = tid - NPAIR0; h < NH_A; h += EXTRA) halo_item(kp, bk, h, lds);
+    } else {
+      for (int h = NH_A + tid; h < NHALO; h += NPAIR0) halo_item(kp, bk, h, lds);
+    }
+  }
+
+  static VSL_DEV void halo_item(const KParams& kp, const Block& bk, int h, float* lds) {
+    int ry, rx;
+    if (h < 2 * R2W) {  // two top rows
+      ry = h / R2W;
+      rx = h % R2W;
+    } else if (h < 4 * R2W) {  // two bottom rows
+      ry = TH + 2 + (h - 2 * R2W) / R2W;
+      rx = (h - 2 * R2W) % R2W;
+    } else {  // left / right two columns of the middle rows
+      const int m = h - 4 * R2W;
+      ry = 2 + m / 4;
+      const int c = m % 4;
+      rx = (c < 2) ? c : TW + c;
+    }
+    warp_position(kp, bk, ry, rx, lds, nullptr);
+  }
+
+  // ---- window helpers ---------------------------------------------------------
+  // 3 rows x 4 columns starting at float offset `base` (even) of a plane with the given pitch
+  static VSL_DEV void load_win(const float* plane, int base, int pitch, float w[3][4]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float2v a = *reinterpret_cast<const float2v*>(plane + base + r * pitch);
+      const float2v c = *reinterpret_cast<const float2v*>(plane + base + r * pitch + 2);
+      w[r][0] = a.x;
+      w[r][1] = a.y;
+      w[r][2] = c.x;
+      w[r][3] = c.y;
+    }
+  }
+  // centred window sums of the target for pixel k of the pair (centre excluded)
+  static VSL_DEV void y_side(const float yw[3][4], int k, float dy[8], float& sy, float& syy) {
+    const float cy = yw[1][1 + k];
+    sy = 0.0f;
+    syy = 0.0f;
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        if (i == 1 && o == 1) continue;
+        const float e = yw[i][k + o] - cy;
+        dy[n++] = e;
+        sy += e;
+        syy = fmaf(e, e, syy);
+      }
+  }
+
+  struct SsimOut {
+    float f;        // clamp((1 - SSIM)/2, 0, 1)
+    float A, B, G;  // d f / d x_j = (A + B x_j + G y_j) / 9 for j in the window
+  };
+
+  // layers.py:252-262 on shift-invariant (window-centre-relative) moments
+  static VSL_DEV SsimOut ssim_pixel(const float xw[3][4], int k, const float dy[8], float cy, float sy, float syy,
+                                    bool want_coef) {
+    const float cx = xw[1][1 + k];
+    float sx = 0.0f, sxx = 0.0f, sxy = 0.0f;
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        if (i == 1 && o == 1) continue;
+        const float e = xw[i][k + o] - cx;
+        sx += e;
+        sxx = fmaf(e, e, sxx);
+        sxy = fmaf(e, dy[n++], sxy);
+      }
+    constexpr float i9 = 1.0f / 9.0f;
+    const float mxp = sx * i9, myp = sy * i9;
+    const float mux = cx + mxp, muy = cy + myp;
+    const float vx = fmaf(sxx, i9, -mxp * mxp);
+    const float vy = fmaf(syy, i9, -myp * myp);
+    const float cxy = fmaf(sxy, i9, -mxp * myp);
+    const float n1 = fmaf(2.0f * mux, muy, kC1);
+    const float n2 = fmaf(2.0f, cxy, kC2);
+    const float d1 = fmaf(mux, mux, fmaf(muy, muy, kC1));
+    const float d2 = vx + vy + kC2;
+    const float inv = fast_rcp(d1 * d2);
+    const float val = fmaf(-0.5f * n1, n2 * inv, 0.5f);
+    SsimOut o;
+    o.f = fminf(fmaxf(val, 0.0f), 1.0f);
+    o.A = o.B = o.G = 0.0f;
+    if (want_coef && val >= 0.0f && val <= 1.0f) {
+      const float t = n2 * inv;              // n2 / (d1 d2)
+      const float inv_d1 = inv * d2, inv_d2 = inv * d1;
+      const float a = -t * (muy - n1 * mux * inv_d1);
+      const float bq = n1 * t * inv_d2;
+      const float g = -n1 * inv;
+      o.A = a - bq * mux - g * muy;
+      o.B = bq;
+      o.G = g;
+    }
+    return o;
+  }
+
+  struct PairPos {
+    int qy, qx0;       // R1 coordinates of the left pixel of the pair
+    int gy, gx[2];     // image coordinates
+    bool valid[2];     // inside the image
+    bool interior[2];  // inside the tile proper (and the image)
+  };
+
+  static VSL_DEV PairPos pair1(const KParams& kp, const Block& bk, int item) {
+    PairPos p;
+    p.qy = item / (R1W / 2);
+    p.qx0 = 2 * (item % (R1W / 2));
+    p.gy = bk.y0 - 1 + p.qy;
+    const bool rowv = p.gy >= 0 && p.gy < kp.H;
+    const bool rowi = p.qy >= 1 && p.qy <= TH;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      p.gx[k] = bk.x0 - 1 + p.qx0 + k;
+      p.valid[k] = rowv && p.gx[k] >= 0 && p.gx[k] < kp.W;
+      p.interior[k] = p.valid[k] && rowi && (p.qx0 + k) >= 1 && (p.qx0 + k) <= TW;
+    }
+    return p;
+  }
+
+  // per-thread carry between phase 2a and 2b (kept in registers / ThreadState is not needed
+  // because both run in the same function on the device; the host build calls them back to back
+  // per thread as well, with a block-wide barrier in between, so the carry lives in `Min2`)
+  struct Min2 {
+    float best[2];
+    float idsum[2];  // AVG: running sum of identity errors
+  };
+
+  // ---- phase 2a: identity reprojection -----------------------------------------
+  static VSL_DEV void phase2a(const KParams& kp, const Block& bk, int tid, const float* lds, Min2& mn) {
+    mn.best[0] = mn.best[1] = INFINITY;
+    mn.idsum[0] = mn.idsum[1] = 0.0f;
+    if (!kp.automask || tid >= NPAIR1) return;
+    const PairPos pp = pair1(kp, bk, tid);
+    const int base = pp.qy * R2W + pp.qx0;
+    float fsum[S][2], lsum[S][2];
+#pragma unroll
+    for (int s = 0; s < S; ++s) fsum[s][0] = fsum[s][1] = lsum[s][0] = lsum[s][1] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float yw[3][4];
+      load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
+      float dy[2][8], sy[2], syy[2];
+      if (!kp.no_ssim) {
+        y_side(yw, 0, dy[0], sy[0], syy[0]);
+        y_side(yw, 1, dy[1], sy[1], syy[1]);
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float xw[3][4];
+        load_win(lds + OFF_U + (s * 3 + c) * P2, base, R2W, xw);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          lsum[s][k] += fabsf(yw[1][1 + k] - xw[1][1 + k]);
+          if (!kp.no_ssim) fsum[s][k] += ssim_pixel(xw, k, dy[k], yw[1][1 + k], sy[k], syy[k], false).f;
+        }
+      }
+    }
+    const size_t HW = (size_t)kp.H * kp.W;
+    constexpr int NI = AVG ? 1 : S;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!pp.valid[k]) continue;
+      const size_t pix = (size_t)pp.gy * kp.W + pp.gx[k];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float e = kp.no_ssim ? lsum[s][k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[s][k], kp.l1_w3 * lsum[s][k]);
+        if (AVG) {
+          mn.idsum[k] += e;
+        } else {
+          const size_t ni = ((size_t)bk.b * NI + s) * HW + pix;
+          const float z = kp.noise ? kp.noise[ni] : hash_normal(kp.seed, ni);
+          const float v = e + z * 0.00001f;
+          if (v < mn.best[k]) mn.best[k] = v;
+        }
+      }
+      if (AVG) {
+        const size_t ni = (size_t)bk.b * HW + pix;
+        const float z = kp.noise ? kp.noise[ni] : hash_normal(kp.seed, ni);
+        mn.best[k] = mn.idsum[k] * (1.0f / S) + z * 0.00001f;
+      }
+    }
+  }
+
+  // ---- phase 2b: warped sources, running argmin, coefficients -----------------
+  static VSL_DEV void phase2b(const KParams& kp, const Block& bk, int tid, float* lds, const Min2& mn,
+                              ThreadState<S>& st) {
+    if (tid >= NPAIR1) return;
+    const PairPos pp = pair1(kp, bk, tid);
+    const int base = pp.qy * R2W + pp.qx0;
+    const int q1 = pp.qy * R1W + pp.qx0;
+    float* coef = lds + OFF_U;            // [NSET][9][P1]
+    float* sel = lds + OFF_U + NSET * 9 * P1;  // [P1] winner (source index, -1 = none) / AVG: 1 = warped wins
+    float best[2] = {mn.best[0], mn.best[1]};
+    float win[2] = {-1.0f, -1.0f};
+    float rsum[2] = {0.0f, 0.0f};
+    if (!AVG) {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) *reinterpret_cast<float2v*>(coef + e * P1 + q1) = float2v{0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      float fsum[2] = {0.0f, 0.0f}, lsum[2] = {0.0f, 0.0f};
+      float cf[2][9];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float yw[3][4], xw[3][4];
+        load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
+        load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          lsum[k] += fabsf(yw[1][1 + k] - xw[1][1 + k]);
+          cf[k][c * 3 + 0] = cf[k][c * 3 + 1] = cf[k][c * 3 + 2] = 0.0f;
+          if (!kp.no_ssim) {
+            float dy[8], sy, syy;
+            y_side(yw, k, dy, sy, syy);
+            const SsimOut o = ssim_pixel(xw, k, dy, yw[1][1 + k], sy, syy, kp.want_grad != 0);
+            fsum[k] += o.f;
+            cf[k][c * 3 + 0] = o.A;
+            cf[k][c * 3 + 1] = o.B;
+            cf[k][c * 3 + 2] = o.G;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float e = kp.no_ssim ? lsum[k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[k], kp.l1_w3 * lsum[k]);
+        e *= kp.warp_scale;
+        if (AVG) {
+          rsum[k] += e;
+#pragma unroll
+          for (int j = 0; j < 9; ++j) coef[(s * 9 + j) * P1 + q1 + k] = pp.valid[k] ? cf[k][j] : 0.0f;
+        } else if (pp.valid[k] && e < best[k]) {
+          best[k] = e;
+          win[k] = (float)s;
+#pragma unroll
+          for (int j = 0; j < 9; ++j) coef[j * P1 + q1 + k] = cf[k][j];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (AVG) {
+        const float e = rsum[k] * (1.0f / S);
+        win[k] = -1.0f;
+        if (pp.valid[k] && e < best[k]) {
+          best[k] = e;
+          win[k] = 1.0f;
+        }
+      }
+      sel[q1 + k] = win[k];
+      if (pp.interior[k]) {
+        st.part[0] += best[k];
+        if (kp.automask && kp.ident_sel)
+          kp.ident_sel[((size_t)bk.b * kp.H + pp.gy) * kp.W + pp.gx[k]] = (win[k] >= 0.0f) ? 1.0f : 0.0f;
+      }
+    }
+  }
+
+  // ---- phase 3: gradients of the interior pair ---------------------------------
+  static VSL_DEV void phase3(const KParams& kp, const Block& bk, int tid, const float* lds, ThreadState<S>& st) {
+    if (tid >= NPAIR0) return;
+    const int H = kp.H, W = kp.W;
+    const int iy = tid / (TW / 2), ip = tid % (TW / 2);
+    const int jy = bk.y0 + iy;
+    if (jy >= H) return;
+    const int jx0 = bk.x0 + 2 * ip;
+    if (jx0 >= W) return;
+    const bool ok[2] = {true, jx0 + 1 < W};
+    const float* coef = lds + OFF_U;
+    const float* sel = lds + OFF_U + NSET * 9 * P1;
+    const int qb = iy * R1W + 2 * ip;  // R1 offset of the window's top-left (even)
+    const size_t HW = (size_t)H * W;
+
+    float g_disp[2] = {0.0f, 0.0f};
+    if (kp.want_grad) {
+      // reflection-padding fold: a window on the image border counts twice for the
+      // pixel next to the border (layers.py:240,249-250 backward)
+      float fy[3], fxm[2][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) fy[i] = 1.0f + (float)(jy == 1 && i == 0) + (float)(jy == H - 2 && i == 2);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+          fxm[k][o] = 1.0f + (float)(jx0 + k == 1 && o == 0) + (float)(jx0 + k == W - 2 && o == 2);
+
+      float selw[3][4];
+      load_win(sel, qb, R1W, selw);
+      float acc[S][2][9];
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int j = 0; j < 9; ++j) acc[s][k][j] = 0.0f;
+
+      if (!kp.no_ssim) {
+        if (AVG) {
+#pragma unroll
+          for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+              float cw[3][4];
+              load_win(coef + (s * 9 + j) * P1, qb, R1W, cw);
+#pragma unroll
+              for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                  for (int o = 0; o < 3; ++o) {
+                    const float m = (selw[i][k + o] > 0.0f) ? fy[i] * fxm[k][o] : 0.0f;
+                    acc[s][k][j] = fmaf(m, cw[i][k + o], acc[s][k][j]);
+                  }
+            }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 9; ++j) {
+            float cw[3][4];
+            load_win(coef + j * P1, qb, R1W, cw);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+              for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                  for (int o = 0; o < 3; ++o) {
+                    const float m = (selw[i][k + o] == (float)s) ? fy[i] * fxm[k][o] : 0.0f;
+                    acc[s][k][j] = fmaf(m, cw[i][k + o], acc[s][k][j]);
+                  }
+          }
+        }
+      }
+
+      const float* ikm = lds + OFF_MAT + 12 * S;
+      const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (!ok[k]) continue;
+        const int p2 = (2 + iy) * R2W + 2 + 2 * ip + k;
+        const float d = lds[OFF_DSP + p2];
+        const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
+        const float D = VSL_FDIV(1.0f, sd);
+        const float fx = (float)(jx0 + k), fyv = (float)jy;
+        float r[3], Xh[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          r[i] = fmaf(ikm[i * 3 + 2], 1.0f, fmaf(ikm[i * 3 + 1], fyv, ikm[i * 3 + 0] * fx));
+          Xh[i] = D * r[i];
+        }
+        Xh[3] = 1.0f;
+        const float selj = selw[1][1 + k];
+        float gD = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const float picked = AVG ? (float)(selj > 0.0f) : (float)(selj == (float)s);
+          float gix = 0.0f, giy = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float x = lds[OFF_WRP + (s * 3 + c) * P2 + p2];
+            const float y = lds[OFF_TGT + c * P2 + p2];
+            float g = kp.cst_ssim * (acc[s][k][c * 3 + 0] + acc[s][k][c * 3 + 1] * x + acc[s][k][c * 3 + 2] * y);
+            g -= kp.cst_l1 * picked * sgn(y - x);
+            gix = fmaf(g, st.ch[k][s].dpx[c], gix);
+            giy = fmaf(g, st.ch[k][s].dpy[c], giy);
+          }
+          // d ix / d gx = W/2, d gx / d u = 2/(W-1)
+          const float gu = gix * ((float)W / wm1), gv = giy * ((float)H / hm1);
+          const float id = st.ch[k][s].inv_den;
+          const float gc[3] = {gu * id, gv * id, -(gu * st.ch[k][s].u + gv * st.ch[k][s].v) * id};
+          const float* P = lds + OFF_MAT + 12 * s;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const float gX = P[0 * 4 + i] * gc[0] + P[1 * 4 + i] * gc[1] + P[2 * 4 + i] * gc[2];
+            gD = fmaf(gX, r[i], gD);
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st.part[4 + 12 * s + i * 4 + j] = fmaf(gc[i], Xh[j], st.part[4 + 12 * s + i * 4 + j]);
+        }
+        g_disp[k] = gD * (-kp.c_disp * D * D);
+      }
+    }
+
+    // edge-aware smoothness, layers.py:211-226 with the 1/(mean+1e-7) factor applied later
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!ok[k]) continue;
+      const int jx = jx0 + k;
+      const int p2 = (2 + iy) * R2W + 2 + 2 * ip + k;
+      const float d0 = lds[OFF_DSP + p2];
+      float ax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // mean_c |I - I_neighbour| for right, left, down, up
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* tp = lds + OFF_TGT + c * P2;
+        const float i0 = tp[p2];
+        ax[0] += fabsf(i0 - tp[p2 + 1]);
+        ax[1] += fabsf(tp[p2 - 1] - i0);
+        ax[2] += fabsf(i0 - tp[p2 + R2W]);
+        ax[3] += fabsf(tp[p2 - R2W] - i0);
+      }
+      const float dn[4] = {lds[OFF_DSP + p2 + 1], lds[OFF_DSP + p2 - 1], lds[OFF_DSP + p2 + R2W],
+                           lds[OFF_DSP + p2 - R2W]};
+      const bool has[4] = {jx + 1 < W, jx > 0, jy + 1 < H, jy > 0};
+      float e = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (!has[t]) continue;
+        const float w = VSL_EXP(-ax[t] * (1.0f / 3.0f));
+        const float inv_n = (t < 2) ? kp.inv_nx : kp.inv_ny;
+        // right/down edges are owned by this pixel (first operand), left/up by the neighbour
+        const float diff = (t == 0 || t == 2) ? d0 - dn[t] : dn[t] - d0;
+        const float sg = sgn(diff) * w * inv_n;
+        e += (t == 0 || t == 2) ? sg : -sg;
+        if (t == 0) st.part[2] = fmaf(w, fabsf(diff), st.part[2]);
+        if (t == 2) st.part[3] = fmaf(w, fabsf(diff), st.part[3]);
+      }
+      st.part[1] += d0;
+      const size_t o = (size_t)bk.b * HW + (size_t)jy * W + jx;
+      if (kp.want_grad) {
+        kp.gphoto[o] = g_disp[k];
+        kp.gedge[o] = e;
+      }
+    }
+  }
+
+  // ---- phase 4: deterministic block reduction ----------------------------------
+  static constexpr int RED_SPLIT = 8;
+  static VSL_DEV void phase4_store(int tid, float* lds, const ThreadState<S>& st) {
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) lds[k * RED_PITCH + tid] = st.part[k];
+  }
+  // after a barrier: item (row, part) sums every RED_SPLIT-th element of a row in a fixed order
+  static VSL_DEV void phase4_sum_a(int tid, float* lds) {
+    for (int item = tid; item < NPART * RED_SPLIT; item += NT) {
+      const int row = item / RED_SPLIT, part = item % RED_SPLIT;
+      const float* r = lds + row * RED_PITCH;
+      float s0 = 0.0f, s1 = 0.0f;
+      int t = part;
+      for (; t + RED_SPLIT < NT; t += 2 * RED_SPLIT) {
+        s0 += r[t];
+        s1 += r[t + RED_SPLIT];
+      }
+      if (t < NT) s0 += r[t];
+      lds[RED_FLOATS + item] = s0 + s1;
+    }
+  }
+  // after another barrier: thread k < NPART adds the RED_SPLIT pieces of row k
+  static VSL_DEV void phase4_sum_b(const KParams& kp, int block_linear, int tid, const float* lds) {
+    if (tid >= NPART) return;
+    const float* r = lds + RED_FLOATS + tid * RED_SPLIT;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < RED_SPLIT; ++i) s += r[i];
+    kp.partials[(size_t)block_linear * kPartStride + tid] = s;
+  }
+};
+
+}  // namespace vsl

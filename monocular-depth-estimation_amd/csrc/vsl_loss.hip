@@ -1,0 +1,398 @@
+// libvsloss.so -- kernels and C-ABI entry points of the fused view-synthesis loss.
+//
+//   vsl_fused_kernel     one workgroup per 32x16 tile; the tile program of vsl_fused.hpp
+//   vsl_finalize_kernel  one workgroup per image: deterministic float64 reduction of the
+//                        tile records, per-image smoothness factors, pose gradients; the
+//                        last workgroup to finish writes the loss scalars
+//   vsl_grad_kernel      elementwise: d total / d disp from the photometric and the
+//                        smoothness parts, scaled by the upstream gradient
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/vsloss.h"
+#include "vsl_fused.hpp"
+
+namespace {
+
+using namespace vsl;
+
+constexpr int kTW = 32, kTH = 16, kNT = 320;
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+// --------------------------------------------------------------------------
+// fused tile kernel
+// --------------------------------------------------------------------------
+template <int S, bool AVG>
+__global__ __launch_bounds__(kNT) void vsl_fused_kernel(const KParams kp) {
+  using F = Fused<kTW, kTH, kNT, S, AVG>;
+  extern __shared__ __align__(16) float lds[];
+  const int tid = threadIdx.x;
+  typename F::Block bk;
+  bk.b = blockIdx.z;
+  bk.x0 = blockIdx.x * kTW;
+  bk.y0 = blockIdx.y * kTH;
+  const int block_linear = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+
+  ThreadState<S> st;
+  typename F::Min2 mn;
+  F::phase0(kp, bk, tid, lds);
+  __syncthreads();
+  F::phase1(kp, bk, tid, lds, st);
+  __syncthreads();
+  F::phase2a(kp, bk, tid, lds, mn);
+  __syncthreads();
+  F::phase2b(kp, bk, tid, lds, mn, st);
+  __syncthreads();
+  F::phase3(kp, bk, tid, lds, st);
+  __syncthreads();
+  F::phase4_store(tid, lds, st);
+  __syncthreads();
+  F::phase4_sum_a(tid, lds);
+  __syncthreads();
+  F::phase4_sum_b(kp, block_linear, tid, lds);
+}
+
+// --------------------------------------------------------------------------
+// finalize
+// --------------------------------------------------------------------------
+struct FinalizeParams {
+  int B, H, W, S;
+  int tiles_per_image;
+  int n_scales;
+  float scale_weight[VSL_MAX_SCALES];
+  float photo_w, smooth_w;  // weights of the two terms in the total
+  double inv_nx, inv_ny;
+  const float* partials;
+  const float* K;
+  double* img;        // [B][4]: photo sum, smoothness term, c1, c2
+  float* gT;          // [kMaxSrc][B][16]
+  float* c12;         // [B][2] float copies of c1, c2 for the gradient kernel
+  unsigned int* counter;
+  float* losses;      // [VSL_LOSS_SLOTS]
+};
+
+__global__ __launch_bounds__(256) void vsl_finalize_kernel(const FinalizeParams fp) {
+  __shared__ double red[4][64];
+  __shared__ double tot[64];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int v = tid & 63, r = tid >> 6;
+  const int npart = num_partials(fp.S);
+  double acc = 0.0;
+  if (v < npart) {
+    const float* base = fp.partials + (size_t)b * fp.tiles_per_image * kPartStride + v;
+    for (int t = r; t < fp.tiles_per_image; t += 4) acc += (double)base[(size_t)t * kPartStride];
+  }
+  red[r][v] = acc;
+  __syncthreads();
+  if (tid < 64) tot[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  __syncthreads();
+
+  const double HW = (double)fp.H * fp.W;
+  if (tid < fp.S * 16) {
+    // d total / d T[k][j] = sum_{i<3} K[i][k] * dP[i][j]   (P = (K @ T)[:3,:], layers.py:189)
+    const int s = tid / 16, k = (tid % 16) / 4, j = tid % 4;
+    const float* Kb = fp.K + 16 * b;
+    double g = 0.0;
+    for (int i = 0; i < 3; ++i) g += (double)Kb[i * 4 + k] * tot[4 + 12 * s + i * 4 + j];
+    fp.gT[((size_t)s * fp.B + b) * 16 + (tid % 16)] = (float)g;
+  }
+  if (tid == 0) {
+    const double mean = tot[1] / HW;
+    const double me = mean + 1e-7;  // Trainer.py:610
+    const double edge = tot[2] * fp.inv_nx + tot[3] * fp.inv_ny;
+    const double c1 = (double)fp.smooth_w / me;
+    const double c2 = (double)fp.smooth_w * edge / (me * me * HW);
+    fp.img[b * 4 + 0] = tot[0];
+    fp.img[b * 4 + 1] = edge / me;
+    fp.c12[b * 2 + 0] = (float)c1;
+    fp.c12[b * 2 + 1] = (float)c2;
+    // publish, then take a ticket; the last image's workgroup assembles the scalars
+    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int ticket = atomicAdd(fp.counter, 1u);
+    const int last = (ticket == (unsigned int)(fp.B - 1));
+    if (last) {
+      __threadfence();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      double photo = 0.0, smooth = 0.0;
+      for (int i = 0; i < fp.B; ++i) {
+        photo += __hip_atomic_load(&fp.img[i * 4 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        smooth += __hip_atomic_load(&fp.img[i * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      photo /= (double)fp.B * HW;
+      fp.losses[VSL_LOSS_TOTAL] = (float)((double)fp.photo_w * photo + (double)fp.smooth_w * smooth);
+      fp.losses[VSL_LOSS_PHOTO] = (float)photo;
+      fp.losses[VSL_LOSS_SMOOTH] = (float)smooth;
+      for (int i = 0; i < VSL_MAX_SCALES; ++i)
+        fp.losses[VSL_LOSS_SCALE0 + i] = (i < fp.n_scales) ? (float)(photo + (double)fp.scale_weight[i] * smooth) : 0.0f;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// gradient assembly
+// --------------------------------------------------------------------------
+struct GradParams {
+  int B, HW, S;
+  const float* gphoto;
+  const float* gedge;
+  const float* c12;
+  const float* gT;
+  const float* grad_losses;  // [VSL_LOSS_SLOTS] upstream gradients or null
+  int n_scales;
+  float scale_weight[VSL_MAX_SCALES];
+  float photo_w, smooth_w;  // weights baked into gphoto / c1, c2 by the forward pass
+  float* grad_disp;
+  float* grad_T[kMaxSrc];
+};
+
+__global__ __launch_bounds__(256) void vsl_grad_kernel(const GradParams gp) {
+  // Every loss slot is a combination of the photometric mean and the smoothness term, so the
+  // upstream gradients collapse to one factor for each of the two stored gradient parts.
+  float ap = 1.0f, as = 1.0f;
+  if (gp.grad_losses) {
+    const float* g = gp.grad_losses;
+    float wp = g[VSL_LOSS_TOTAL] * gp.photo_w + g[VSL_LOSS_PHOTO];
+    float ws = g[VSL_LOSS_TOTAL] * gp.smooth_w + g[VSL_LOSS_SMOOTH];
+    for (int i = 0; i < gp.n_scales; ++i) {
+      wp += g[VSL_LOSS_SCALE0 + i];
+      ws += g[VSL_LOSS_SCALE0 + i] * gp.scale_weight[i];
+    }
+    ap = wp / gp.photo_w;
+    as = gp.smooth_w != 0.0f ? ws / gp.smooth_w : 0.0f;
+  }
+  const int b = blockIdx.y;
+  if (gp.grad_disp) {
+    const float c1 = as * gp.c12[b * 2 + 0], c2 = as * gp.c12[b * 2 + 1];
+    const size_t off = (size_t)b * gp.HW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < gp.HW; i += gridDim.x * blockDim.x)
+      gp.grad_disp[off + i] = ap * gp.gphoto[off + i] + (c1 * gp.gedge[off + i] - c2);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < gp.S * 16) {
+    const int s = threadIdx.x / 16, e = threadIdx.x % 16;
+    if (gp.grad_T[s]) gp.grad_T[s][b * 16 + e] = ap * gp.gT[((size_t)s * gp.B + b) * 16 + e];
+  }
+}
+
+// --------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct Layout {
+  int tiles_x, tiles_y, tiles_per_image, blocks;
+  size_t off_partials, off_gphoto, off_gedge, off_img, off_gT, off_c12, off_counter, total;
+};
+
+Layout make_layout(int B, int H, int W) {
+  Layout L;
+  L.tiles_x = (W + kTW - 1) / kTW;
+  L.tiles_y = (H + kTH - 1) / kTH;
+  L.tiles_per_image = L.tiles_x * L.tiles_y;
+  L.blocks = L.tiles_per_image * B;
+  size_t o = 0;
+  L.off_counter = o;
+  o += 256;
+  L.off_partials = o;
+  o += align256((size_t)L.blocks * kPartStride * sizeof(float));
+  L.off_gphoto = o;
+  o += align256((size_t)B * H * W * sizeof(float));
+  L.off_gedge = o;
+  o += align256((size_t)B * H * W * sizeof(float));
+  L.off_img = o;
+  o += align256((size_t)B * 4 * sizeof(double));
+  L.off_gT = o;
+  o += align256((size_t)kMaxSrc * B * 16 * sizeof(float));
+  L.off_c12 = o;
+  o += align256((size_t)B * 2 * sizeof(float));
+  L.total = o;
+  return L;
+}
+
+int check_desc(const vsl_loss_desc* d) {
+  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
+  if (d->B < 1 || d->H < 2 || d->W < 2) return fail(VSL_ERR_INVALID_ARGUMENT, "need B >= 1, H >= 2, W >= 2");
+  if (d->B > 65535) return fail(VSL_ERR_INVALID_ARGUMENT, "B exceeds 65535");
+  if ((long long)d->B * d->H * d->W * 3 >= (1ll << 31))
+    return fail(VSL_ERR_INVALID_ARGUMENT, "B*3*H*W must stay below 2^31");
+  if (d->S < 1 || d->S > VSL_MAX_SOURCES) return fail(VSL_ERR_INVALID_ARGUMENT, "S must be 1..VSL_MAX_SOURCES");
+  if (d->n_scales < 1 || d->n_scales > VSL_MAX_SCALES)
+    return fail(VSL_ERR_INVALID_ARGUMENT, "n_scales must be 1..VSL_MAX_SCALES");
+  if (!(d->min_depth > 0.0f) || !(d->max_depth > d->min_depth))
+    return fail(VSL_ERR_INVALID_ARGUMENT, "need 0 < min_depth < max_depth");
+  if (!d->disp || !d->target || !d->K || !d->inv_K) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL input tensor");
+  for (int s = 0; s < d->S; ++s)
+    if (!d->source[s] || !d->T[s]) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL source image or pose");
+  return VSL_OK;
+}
+
+template <int S, bool AVG>
+int launch_fused(const KParams& kp, dim3 grid, hipStream_t stream) {
+  using F = Fused<kTW, kTH, kNT, S, AVG>;
+  constexpr size_t lds_bytes = (size_t)F::LDS_FLOATS * sizeof(float);
+  static_assert(lds_bytes <= 160 * 1024, "tile does not fit the 160 KiB LDS of a CU");
+  static thread_local bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vsl_fused_kernel<S, AVG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+      return fail(VSL_ERR_LAUNCH_FAILED, "hipFuncSetAttribute(max dynamic LDS) failed");
+    configured = true;
+  }
+  hipLaunchKernelGGL((vsl_fused_kernel<S, AVG>), grid, dim3(kNT), lds_bytes, stream, kp);
+  return VSL_OK;
+}
+
+template <int S>
+int launch_fused_s(const KParams& kp, bool avg, dim3 grid, hipStream_t stream) {
+  return avg ? launch_fused<S, true>(kp, grid, stream) : launch_fused<S, false>(kp, grid, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vsl_last_error_string(void) { return g_err.c_str(); }
+
+int vsl_version(void) { return 100; }
+
+size_t vsl_loss_workspace_bytes(const vsl_loss_desc* d) {
+  if (!d || d->B < 1 || d->H < 1 || d->W < 1) return 0;
+  return make_layout(d->B, d->H, d->W).total;
+}
+
+int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes, float* losses,
+                     float* identity_selection, void* stream_) {
+  if (int rc = check_desc(d)) return rc;
+  if (!workspace || !losses) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace and losses must not be NULL");
+  if (((uintptr_t)workspace & 255) != 0) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+  const Layout L = make_layout(d->B, d->H, d->W);
+  if (workspace_bytes < L.total) return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "workspace smaller than vsl_loss_workspace_bytes()");
+  hipStream_t stream = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+
+  const bool avg = (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0;
+  const bool automask = (d->flags & VSL_FLAG_AUTOMASK) != 0;
+  const bool no_ssim = (d->flags & VSL_FLAG_NO_SSIM) != 0;
+  const bool want_grad = (d->flags & VSL_FLAG_NO_GRAD) == 0;
+
+  float smooth_sum = 0.0f;
+  for (int i = 0; i < d->n_scales; ++i) smooth_sum += d->scale_weight[i];
+  const float photo_w = (float)d->n_scales * d->inv_num_scales;
+  const float smooth_w = smooth_sum * d->inv_num_scales;
+  const double npix = (double)d->B * d->H * d->W;
+
+  KParams kp{};
+  kp.B = d->B;
+  kp.H = d->H;
+  kp.W = d->W;
+  kp.S = d->S;
+  kp.automask = automask;
+  kp.no_ssim = no_ssim;
+  // python floats: min_disp = 1/max_depth, (max_disp - min_disp), then cast to float32 (layers.py:21-23)
+  kp.a_disp = (float)(1.0 / (double)d->max_depth);
+  kp.c_disp = (float)(1.0 / (double)d->min_depth - 1.0 / (double)d->max_depth);
+  kp.eps = d->eps;
+  const double base = (double)d->warp_scale * photo_w / npix / (avg ? (double)d->S : 1.0);
+  kp.cst_ssim = no_ssim ? 0.0f : (float)(base * d->ssim_weight / 27.0);
+  kp.cst_l1 = no_ssim ? (float)(base / 3.0) : (float)(base * d->l1_weight / 3.0);
+  kp.ssim_w3 = d->ssim_weight / 3.0f;
+  kp.l1_w3 = d->l1_weight / 3.0f;
+  kp.warp_scale = d->warp_scale;
+  kp.inv_nx = (float)(1.0 / ((double)d->B * d->H * (d->W - 1)));
+  kp.inv_ny = (float)(1.0 / ((double)d->B * (d->H - 1) * d->W));
+  kp.disp = d->disp;
+  kp.tgt = d->target;
+  kp.K = d->K;
+  kp.invK = d->inv_K;
+  for (int s = 0; s < kMaxSrc; ++s) {
+    kp.src[s] = s < d->S ? d->source[s] : nullptr;
+    kp.T[s] = s < d->S ? d->T[s] : nullptr;
+  }
+  kp.noise = d->noise;
+  kp.seed = d->seed;
+  kp.gphoto = (float*)(ws + L.off_gphoto);
+  kp.gedge = (float*)(ws + L.off_gedge);
+  kp.ident_sel = identity_selection;
+  kp.partials = (float*)(ws + L.off_partials);
+  kp.want_grad = want_grad;
+  kp.counter = (unsigned int*)(ws + L.off_counter);
+
+  const dim3 grid(L.tiles_x, L.tiles_y, d->B);
+  int rc = VSL_OK;
+  switch (d->S) {
+    case 1: rc = launch_fused_s<1>(kp, avg, grid, stream); break;
+    case 2: rc = launch_fused_s<2>(kp, avg, grid, stream); break;
+    case 3: rc = launch_fused_s<3>(kp, avg, grid, stream); break;
+    default: rc = launch_fused_s<4>(kp, avg, grid, stream); break;
+  }
+  if (rc) return rc;
+
+  FinalizeParams fp{};
+  fp.B = d->B;
+  fp.H = d->H;
+  fp.W = d->W;
+  fp.S = d->S;
+  fp.tiles_per_image = L.tiles_per_image;
+  fp.n_scales = d->n_scales;
+  for (int i = 0; i < VSL_MAX_SCALES; ++i) fp.scale_weight[i] = i < d->n_scales ? d->scale_weight[i] : 0.0f;
+  fp.photo_w = photo_w;
+  fp.smooth_w = smooth_w;
+  fp.inv_nx = 1.0 / ((double)d->B * d->H * (d->W - 1));
+  fp.inv_ny = 1.0 / ((double)d->B * (d->H - 1) * d->W);
+  fp.partials = kp.partials;
+  fp.K = d->K;
+  fp.img = (double*)(ws + L.off_img);
+  fp.gT = (float*)(ws + L.off_gT);
+  fp.c12 = (float*)(ws + L.off_c12);
+  fp.counter = (unsigned int*)(ws + L.off_counter);
+  fp.losses = losses;
+  hipLaunchKernelGGL(vsl_finalize_kernel, dim3(d->B), dim3(256), 0, stream, fp);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess)
+    return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  return VSL_OK;
+}
+
+int vsl_loss_backward(const vsl_loss_desc* d, const void* workspace, size_t workspace_bytes,
+                      const float* grad_losses, float* grad_disp, float* const* grad_T, void* stream_) {
+  if (int rc = check_desc(d)) return rc;
+  if (d->flags & VSL_FLAG_NO_GRAD) return fail(VSL_ERR_INVALID_ARGUMENT, "forward ran with VSL_FLAG_NO_GRAD");
+  if (!workspace) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace must not be NULL");
+  const Layout L = make_layout(d->B, d->H, d->W);
+  if (workspace_bytes < L.total) return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "workspace smaller than vsl_loss_workspace_bytes()");
+  const char* ws = (const char*)workspace;
+  GradParams gp{};
+  gp.B = d->B;
+  gp.HW = d->H * d->W;
+  gp.S = d->S;
+  gp.gphoto = (const float*)(ws + L.off_gphoto);
+  gp.gedge = (const float*)(ws + L.off_gedge);
+  gp.c12 = (const float*)(ws + L.off_c12);
+  gp.gT = (const float*)(ws + L.off_gT);
+  gp.grad_losses = grad_losses;
+  gp.n_scales = d->n_scales;
+  float smooth_sum = 0.0f;
+  for (int i = 0; i < VSL_MAX_SCALES; ++i) {
+    gp.scale_weight[i] = i < d->n_scales ? d->scale_weight[i] : 0.0f;
+    smooth_sum += gp.scale_weight[i];
+  }
+  gp.photo_w = (float)d->n_scales * d->inv_num_scales;
+  gp.smooth_w = smooth_sum * d->inv_num_scales;
+  gp.grad_disp = grad_disp;
+  for (int s = 0; s < kMaxSrc; ++s) gp.grad_T[s] = (grad_T && s < d->S) ? grad_T[s] : nullptr;
+  int bx = (gp.HW + 255) / 256;
+  if (bx > 512) bx = 512;
+  hipLaunchKernelGGL(vsl_grad_kernel, dim3(bx, d->B), dim3(256), 0, (hipStream_t)stream_, gp);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess)
+    return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  return VSL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+"""Autograd bindings of the fused view-synthesis loss (C-ABI: include/vsloss.h).
+
+``fused_view_synthesis_loss`` evaluates, for one disparity tensor, what
+``Trainer.generate_images_pred`` + ``Trainer.compute_losses`` compute
+(Python/Trainer.py:419-620 of the reference) and is differentiable with respect
+to the disparity and the pose matrices.  The forward launch already prepares
+the gradients; ``backward`` is a single elementwise kernel that applies the
+upstream gradient.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _abi
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (the loss has no CPU implementation)" % name)
+    if t.dtype != torch.float32:
+        t = t.float()          # the reference feeds float64 images (data_loaders.py:338-341); cast on load
+    return t.contiguous()
+
+
+class _FusedLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, disp, *poses):
+        desc = _abi.LossDesc()
+        B, _, H, W = disp.shape
+        S = len(poses)
+        desc.B, desc.H, desc.W, desc.S = B, H, W, S
+        desc.flags = cfg["flags"] | (0 if cfg["want_grad"] else _abi.FLAG_NO_GRAD)
+        desc.min_depth, desc.max_depth, desc.eps = cfg["min_depth"], cfg["max_depth"], 1e-7
+        desc.ssim_weight, desc.l1_weight, desc.warp_scale = 0.85, 0.15, cfg["warp_scale"]
+        sw = cfg["scale_weights"]
+        desc.n_scales = len(sw)
+        for i, w in enumerate(sw):
+            desc.scale_weight[i] = w
+        desc.inv_num_scales = cfg["inv_num_scales"]
+        keep = [disp, cfg["target"], cfg["K"], cfg["inv_K"]] + list(cfg["sources"]) + list(poses)
+        desc.disp, desc.target = disp.data_ptr(), cfg["target"].data_ptr()
+        desc.K, desc.inv_K = cfg["K"].data_ptr(), cfg["inv_K"].data_ptr()
+        for s in range(S):
+            desc.source[s] = cfg["sources"][s].data_ptr()
+            desc.T[s] = poses[s].data_ptr()
+        if cfg["noise"] is not None:
+            desc.noise = cfg["noise"].data_ptr()
+            keep.append(cfg["noise"])
+        desc.seed = cfg["seed"]
+
+        nbytes = _abi.lib.vsl_loss_workspace_bytes(ctypes.byref(desc))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=disp.device)
+        losses = torch.empty(_abi.LOSS_SLOTS, dtype=torch.float32, device=disp.device)
+        automask = bool(cfg["flags"] & _abi.FLAG_AUTOMASK)
+        ident = torch.empty(B, H, W, dtype=torch.float32, device=disp.device) if automask else None
+        stream = torch.cuda.current_stream(disp.device).cuda_stream
+        _abi.check(_abi.lib.vsl_loss_forward(ctypes.byref(desc), ws.data_ptr(), nbytes, losses.data_ptr(),
+                                             ident.data_ptr() if ident is not None else None, stream))
+        ctx.desc, ctx.ws, ctx.nbytes, ctx.keep = desc, ws, nbytes, keep
+        ctx.shape = (B, H, W, S)
+        if ident is None:
+            ident = torch.empty(0, device=disp.device)
+        ctx.mark_non_differentiable(ident)
+        return losses, ident
+
+    @staticmethod
+    def backward(ctx, g_losses, _g_ident):
+        B, H, W, S = ctx.shape
+        dev = ctx.ws.device
+        need = ctx.needs_input_grad  # (cfg, disp, *poses)
+        g_losses = g_losses.contiguous().float()
+        grad_disp = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev) if need[1] else None
+        grad_T = [torch.empty(B, 4, 4, dtype=torch.float32, device=dev) if need[2 + s] else None for s in range(S)]
+        ptrs = (ctypes.c_void_p * _abi.MAX_SOURCES)()
+        for s in range(S):
+            ptrs[s] = grad_T[s].data_ptr() if grad_T[s] is not None else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(_abi.lib.vsl_loss_backward(ctypes.byref(ctx.desc), ctx.ws.data_ptr(), ctx.nbytes,
+                                              g_losses.data_ptr(),
+                                              grad_disp.data_ptr() if grad_disp is not None else None,
+                                              ptrs, stream))
+        return (None, grad_disp) + tuple(grad_T)
+
+
+def fused_view_synthesis_loss(disp: torch.Tensor, target: torch.Tensor, sources: Sequence[torch.Tensor],
+                              K: torch.Tensor, inv_K: torch.Tensor, poses: Sequence[torch.Tensor],
+                              noise: Optional[torch.Tensor] = None, *, automask: bool = True,
+                              avg_reprojection: bool = False, no_ssim: bool = False,
+                              scale_weights: Sequence[float] = (1e-3,), inv_num_scales: float = 1.0,
+                              warp_scale: float = 1.0, min_depth: float = 0.1, max_depth: float = 100.0,
+                              seed: int = 0):
+    """One fused pass of the view-synthesis loss.
+
+    disp [B,1,H,W]; target and every source [B,3,H,W]; K, inv_K and every pose [B,4,4].
+    Returns ``(losses, identity_selection)``: ``losses`` is a float32 vector laid out as
+    ``_abi.LOSS_*`` (total, photometric mean, smoothness, then one "loss/{scale}" per entry
+    of ``scale_weights``); ``identity_selection`` is [B,H,W] (empty without auto-masking).
+    """
+    if disp.dim() != 4 or disp.shape[1] != 1:
+        raise ValueError("disp must be [B,1,H,W]")
+    S = len(sources)
+    if S < 1 or S > _abi.MAX_SOURCES or len(poses) != S:
+        raise ValueError("need 1..%d sources and one pose per source" % _abi.MAX_SOURCES)
+    if not 1 <= len(scale_weights) <= _abi.MAX_SCALES:
+        raise ValueError("need 1..%d scale weights" % _abi.MAX_SCALES)
+    B, _, H, W = disp.shape
+    for t in [target] + list(sources):
+        if tuple(t.shape) != (B, 3, H, W):
+            raise ValueError("images must be [B,3,H,W] matching disp")
+    n_id = 1 if avg_reprojection else S
+    if noise is not None and automask and tuple(noise.shape) != (B, n_id, H, W):
+        raise ValueError("noise must be [B,%d,H,W]" % n_id)
+    flags = (_abi.FLAG_AUTOMASK if automask else 0) | (_abi.FLAG_AVG_REPROJECTION if avg_reprojection else 0) \
+        | (_abi.FLAG_NO_SSIM if no_ssim else 0)
+    poses = [_f32c(p, "pose") for p in poses]
+    disp = _f32c(disp, "disp")
+    want_grad = torch.is_grad_enabled() and (disp.requires_grad or any(p.requires_grad for p in poses))
+    cfg = dict(flags=flags, want_grad=want_grad, min_depth=float(min_depth), max_depth=float(max_depth),
+               warp_scale=float(warp_scale), scale_weights=[float(w) for w in scale_weights],
+               inv_num_scales=float(inv_num_scales), target=_f32c(target, "target"),
+               sources=[_f32c(s, "source") for s in sources], K=_f32c(K, "K"), inv_K=_f32c(inv_K, "inv_K"),
+               noise=_f32c(noise, "noise") if (noise is not None and automask) else None, seed=int(seed))
+    losses, ident = _FusedLossFn.apply(cfg, disp, *poses)
+    return losses, (ident if automask else None)

@@ -1,0 +1,58 @@
+// CPU build of the fused tile program: the threads of a workgroup run one after the
+// other, each phase over all threads before the next (= the barriers of the HIP
+// kernel).  TEST INFRASTRUCTURE: lets address-sanitizer and the parity tests exercise
+// the exact tile logic (indexing, halos, reflection fold, reductions) without a GPU.
+// The shipped library does not contain or call any of this.
+//
+// Build: g++ -O1 -g -std=c++17 -ffp-contract=off -fsanitize=address,undefined -shared -fPIC
+#include <cstring>
+#include <vector>
+
+#include "../../monocular-depth-estimation_amd/csrc/vsl_fused.hpp"
+
+using namespace vsl;
+
+namespace {
+constexpr int kTW = 32, kTH = 16, kNT = 320;
+
+template <int S, bool AVG>
+void run_tiles(KParams kp) {
+  using F = Fused<kTW, kTH, kNT, S, AVG>;
+  const int tx = (kp.W + kTW - 1) / kTW, ty = (kp.H + kTH - 1) / kTH;
+  std::vector<float> lds(F::LDS_FLOATS);
+  std::vector<ThreadState<S>> st(kNT);
+  std::vector<typename F::Min2> mn(kNT);
+  for (int b = 0; b < kp.B; ++b)
+    for (int by = 0; by < ty; ++by)
+      for (int bx = 0; bx < tx; ++bx) {
+        typename F::Block bk{b, bx * kTW, by * kTH};
+        const int lin = (b * ty + by) * tx + bx;
+        // poison LDS so that reads of unwritten cells show up as NaNs in the results
+        for (auto& v : lds) v = NAN;
+        for (int t = 0; t < kNT; ++t) F::phase0(kp, bk, t, lds.data());
+        for (int t = 0; t < kNT; ++t) F::phase1(kp, bk, t, lds.data(), st[t]);
+        for (int t = 0; t < kNT; ++t) F::phase2a(kp, bk, t, lds.data(), mn[t]);
+        for (int t = 0; t < kNT; ++t) F::phase2b(kp, bk, t, lds.data(), mn[t], st[t]);
+        for (int t = 0; t < kNT; ++t) F::phase3(kp, bk, t, lds.data(), st[t]);
+        for (int t = 0; t < kNT; ++t) F::phase4_store(t, lds.data(), st[t]);
+        for (int t = 0; t < kNT; ++t) F::phase4_sum_a(t, lds.data());
+        for (int t = 0; t < kNT; ++t) F::phase4_sum_b(kp, lin, t, lds.data());
+      }
+}
+}  // namespace
+
+extern "C" int vsl_emu_tiles(const KParams* kp, int avg) {
+  switch (kp->S) {
+    case 1: avg ? run_tiles<1, true>(*kp) : run_tiles<1, false>(*kp); break;
+    case 2: avg ? run_tiles<2, true>(*kp) : run_tiles<2, false>(*kp); break;
+    case 3: avg ? run_tiles<3, true>(*kp) : run_tiles<3, false>(*kp); break;
+    case 4: avg ? run_tiles<4, true>(*kp) : run_tiles<4, false>(*kp); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+extern "C" int vsl_emu_part_stride() { return kPartStride; }
+extern "C" int vsl_emu_tile_w() { return kTW; }
+extern "C" int vsl_emu_tile_h() { return kTH; }
+extern "C" int vsl_emu_kparams_size() { return (int)sizeof(KParams); }

@@ -1,0 +1,117 @@
+"""Drive the CPU build of the fused tile program (tests/emu/vsl_emu.cpp) and finish
+the computation (what vsl_finalize_kernel / vsl_grad_kernel do) in numpy.
+Test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "emu")
+EMU_SO = os.path.join(EMU_DIR, "libvsl_emu.so")
+MAX_SRC = 4
+
+
+def build_emu(sanitize=False, force=False):
+    src = os.path.join(EMU_DIR, "vsl_emu.cpp")
+    hdr = os.path.join(HERE, "..", "monocular-depth-estimation_amd", "csrc", "vsl_fused.hpp")
+    out = EMU_SO if not sanitize else os.path.join(EMU_DIR, "libvsl_emu_asan.so")
+    if (not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return out
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", out, src]
+    if sanitize:
+        cmd[1:1] = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+    subprocess.check_call(cmd)
+    return out
+
+
+class KParams(ctypes.Structure):
+    _fields_ = [
+        ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("S", ctypes.c_int),
+        ("automask", ctypes.c_int), ("no_ssim", ctypes.c_int),
+        ("a_disp", ctypes.c_float), ("c_disp", ctypes.c_float), ("eps", ctypes.c_float),
+        ("cst_ssim", ctypes.c_float), ("cst_l1", ctypes.c_float),
+        ("ssim_w3", ctypes.c_float), ("l1_w3", ctypes.c_float), ("warp_scale", ctypes.c_float),
+        ("inv_nx", ctypes.c_float), ("inv_ny", ctypes.c_float),
+        ("disp", ctypes.c_void_p), ("tgt", ctypes.c_void_p), ("src", ctypes.c_void_p * MAX_SRC),
+        ("K", ctypes.c_void_p), ("invK", ctypes.c_void_p), ("T", ctypes.c_void_p * MAX_SRC),
+        ("noise", ctypes.c_void_p), ("seed", ctypes.c_ulonglong),
+        ("gphoto", ctypes.c_void_p), ("gedge", ctypes.c_void_p), ("ident_sel", ctypes.c_void_p),
+        ("partials", ctypes.c_void_p), ("counter", ctypes.c_void_p), ("want_grad", ctypes.c_int),
+    ]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p).value
+
+
+def run_emu(disp, target, sources, K, inv_K, Ts, noise, automask=True, avg=False, no_ssim=False,
+            warp_scale=1.0, scale_weights=(1e-3,), inv_num_scales=1.0, min_depth=0.1, max_depth=100.0,
+            so_path=None, seed=0):
+    """All arrays float32 numpy.  Returns dict(loss, photo, smooth, loss_scales, grad_disp, grad_T, ident_sel)."""
+    lib = ctypes.CDLL(so_path or build_emu())
+    assert lib.vsl_emu_kparams_size() == ctypes.sizeof(KParams), "KParams mirror out of date"
+    B, _, H, W = disp.shape
+    S = len(sources)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    disp, target, K, inv_K = f32(disp), f32(target), f32(K), f32(inv_K)
+    sources = [f32(s) for s in sources]
+    Ts = [f32(t) for t in Ts]
+    noise = f32(noise) if noise is not None else None
+    tw, th, stride = lib.vsl_emu_tile_w(), lib.vsl_emu_tile_h(), lib.vsl_emu_part_stride()
+    tiles = ((W + tw - 1) // tw) * ((H + th - 1) // th)
+    partials = np.full((B * tiles, stride), np.nan, np.float32)
+    gphoto = np.full((B, H, W), np.nan, np.float32)
+    gedge = np.full((B, H, W), np.nan, np.float32)
+    ident = np.full((B, H, W), np.nan, np.float32)
+
+    n_scales = len(scale_weights)
+    photo_w = n_scales * inv_num_scales
+    smooth_w = float(np.float32(sum(np.float32(w) for w in scale_weights))) * inv_num_scales
+    npix = float(B * H * W)
+    kp = KParams()
+    kp.B, kp.H, kp.W, kp.S = B, H, W, S
+    kp.automask, kp.no_ssim = int(automask), int(no_ssim)
+    kp.a_disp = 1.0 / max_depth
+    kp.c_disp = 1.0 / min_depth - 1.0 / max_depth
+    kp.eps = 1e-7
+    base = warp_scale * photo_w / npix / (S if avg else 1.0)
+    kp.cst_ssim = 0.0 if no_ssim else base * 0.85 / 27.0
+    kp.cst_l1 = base / 3.0 if no_ssim else base * 0.15 / 3.0
+    kp.ssim_w3, kp.l1_w3 = 0.85 / 3.0, 0.15 / 3.0
+    kp.warp_scale = warp_scale
+    kp.inv_nx = 1.0 / (B * H * (W - 1))
+    kp.inv_ny = 1.0 / (B * (H - 1) * W)
+    kp.disp, kp.tgt, kp.K, kp.invK = _ptr(disp), _ptr(target), _ptr(K), _ptr(inv_K)
+    for s in range(S):
+        kp.src[s] = _ptr(sources[s])
+        kp.T[s] = _ptr(Ts[s])
+    kp.noise = _ptr(noise) if noise is not None else None
+    kp.seed = seed
+    kp.gphoto, kp.gedge, kp.ident_sel, kp.partials = _ptr(gphoto), _ptr(gedge), _ptr(ident), _ptr(partials)
+    kp.counter = None
+    kp.want_grad = 1
+    rc = lib.vsl_emu_tiles(ctypes.byref(kp), int(avg))
+    assert rc == 0
+
+    # --- what vsl_finalize_kernel computes ---
+    npart = 4 + 12 * S
+    tot = partials[:, :npart].astype(np.float64).reshape(B, tiles, npart).sum(1)   # [B, npart]
+    HW = float(H * W)
+    me = tot[:, 1] / HW + 1e-7
+    edge = tot[:, 2] / (B * H * (W - 1)) + tot[:, 3] / (B * (H - 1) * W)
+    c1 = smooth_w / me
+    c2 = smooth_w * edge / (me * me * HW)
+    photo = tot[:, 0].sum() / npix
+    smooth = (edge / me).sum()
+    total = photo_w * photo + smooth_w * smooth
+    grad_T = []
+    for s in range(S):
+        dP = tot[:, 4 + 12 * s:16 + 12 * s].reshape(B, 3, 4)
+        grad_T.append(np.einsum("bik,bij->bkj", K[:, :3, :].astype(np.float64), dP).astype(np.float32))
+    # --- what vsl_grad_kernel computes (upstream gradient 1) ---
+    grad_disp = (gphoto + (c1.astype(np.float32)[:, None, None] * gedge - c2.astype(np.float32)[:, None, None]))
+    return dict(loss=total, photo=photo, smooth=smooth,
+                loss_scales=[photo + float(np.float32(w)) * smooth for w in scale_weights],
+                grad_disp=grad_disp[:, None], grad_T=grad_T, ident_sel=ident, partials=partials)
