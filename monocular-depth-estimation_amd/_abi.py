@@ -10,7 +10,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvsloss.so")
+LIB_PATH = os.environ.get("VSL_LIBRARY", os.path.join(_HERE, "libvsloss.so"))  # override: A/B builds of the same ABI
 
 MAX_SOURCES = 4
 MAX_SCALES = 8

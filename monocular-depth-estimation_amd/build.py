@@ -23,7 +23,10 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return OUT
-    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+    # -ffp-contract=on: fuse a*b+c only inside one expression.  The default (fast) also fuses
+    # across statements, which measurably moves the pose/disparity gradients away from the
+    # reference's float32 results (1.5e-5 instead of 1e-6 relative on the golden fixtures).
+    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=on", "-shared", "-fPIC",
            "-I", os.path.join(HERE, "..", "include"), "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -44,6 +44,10 @@
 #define VSL_EXP(x) expf(x)
 #endif
 
+#ifndef VSL_NC
+#define VSL_NC 0
+#endif
+
 namespace vsl {
 
 constexpr int kMaxSrc = 4;
@@ -92,7 +96,7 @@ VSL_DEV int reflect_clamp(int i, int n) {
 }
 
 VSL_DEV float fast_rcp(float x) {
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && !defined(VSL_EXACT_RCP)
   float r = __builtin_amdgcn_rcpf(x);
   return fmaf(fmaf(-x, r, 1.0f), r, r);  // one Newton step: ~0.5 ulp
 #else
@@ -209,6 +213,9 @@ struct Fused {
 
   // ---- phase 1: one R2 position --------------------------------------------
   static VSL_DEV void warp_position(const KParams& kp, const Block& bk, int ry, int rx, float* lds, Chain* chain) {
+#if (VSL_NC & 1) && defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     const int H = kp.H, W = kp.W;
     const int py = reflect_clamp(bk.y0 - 2 + ry, H);
     const int px = reflect_clamp(bk.x0 - 2 + rx, W);
@@ -357,6 +364,9 @@ struct Fused {
   // layers.py:252-262 on shift-invariant (window-centre-relative) moments
   static VSL_DEV SsimOut ssim_pixel(const float xw[3][4], int k, const float dy[8], float cy, float sy, float syy,
                                     bool want_coef) {
+#if (VSL_NC & 2) && defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     const float cx = xw[1][1 + k];
     float sx = 0.0f, sxx = 0.0f, sxy = 0.0f;
     int n = 0;
@@ -488,6 +498,9 @@ struct Fused {
   // ---- phase 2b: warped sources, running argmin, coefficients -----------------
   static VSL_DEV void phase2b(const KParams& kp, const Block& bk, int tid, float* lds, const Min2& mn,
                               ThreadState<S>& st) {
+#if (VSL_NC & 8) && defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     if (tid >= NPAIR1) return;
     const PairPos pp = pair1(kp, bk, tid);
     const int base = pp.qy * R2W + pp.qx0;
@@ -562,6 +575,9 @@ struct Fused {
 
   // ---- phase 3: gradients of the interior pair ---------------------------------
   static VSL_DEV void phase3(const KParams& kp, const Block& bk, int tid, const float* lds, ThreadState<S>& st) {
+#if (VSL_NC & 4) && defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     if (tid >= NPAIR0) return;
     const int H = kp.H, W = kp.W;
     const int iy = tid / (TW / 2), ip = tid % (TW / 2);

@@ -35,7 +35,7 @@ def run_fixture(name, image_dtype=torch.float32):
         warp_scale=0.9 if cfg["variant"] == "distil" else 1.0)
     losses[0].backward()
     torch.cuda.synchronize()
-    return cfg, z, srcs, losses.cpu().numpy(), ident, disp.grad.cpu().numpy(), [p.grad.cpu().numpy() for p in poses]
+    return cfg, z, srcs, losses.detach().cpu().numpy(), ident, disp.grad.cpu().numpy(), [p.grad.cpu().numpy() for p in poses]
 
 
 @pytest.mark.parametrize("name", case_names())
