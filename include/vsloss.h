@@ -84,6 +84,9 @@ typedef struct vsl_loss_desc {
                                             noise of Trainer.py:589, or NULL: the kernel then draws it from
                                             a counter-based generator keyed by `seed`               */
   uint64_t seed;
+  const float* identity_min;             /* optional [B,H,W] written by vsl_identity_min for the same images,
+                                            noise/seed and flags (lets several disparity heads share it);
+                                            NULL: vsl_loss_forward computes it itself                  */
 } vsl_loss_desc;
 
 /* Bytes of workspace vsl_loss_forward / vsl_loss_backward need for this shape. */
@@ -97,6 +100,15 @@ size_t vsl_loss_workspace_bytes(const vsl_loss_desc* desc);
  */
 int vsl_loss_forward(const vsl_loss_desc* desc, void* workspace, size_t workspace_bytes, float* losses,
                      float* identity_selection, void* stream);
+
+/*
+ * The part of the auto-mask that depends on neither disparity nor pose: for every
+ * pixel the minimum over the sources of the identity-reprojection error plus
+ * 1e-5 * noise (Trainer.py:553-566,587-590; with VSL_FLAG_AVG_REPROJECTION the mean
+ * over sources).  Reads B,H,W,S, flags, ssim/l1 weights, target, source[], noise/seed.
+ * identity_min is [B,H,W] float32.
+ */
+int vsl_identity_min(const vsl_loss_desc* desc, float* identity_min, void* stream);
 
 /*
  * Backward (the autograd pass that `.backward()` runs over Trainer.py:419-620):

@@ -18,7 +18,7 @@ FLAG_AUTOMASK, FLAG_AVG_REPROJECTION, FLAG_NO_SSIM, FLAG_NO_GRAD = 1, 2, 4, 8
 LOSS_TOTAL, LOSS_PHOTO, LOSS_SMOOTH, LOSS_SCALE0 = 0, 1, 2, 3
 LOSS_SLOTS = 3 + MAX_SCALES
 
-EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward",
+EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", "vsl_identity_min",
            "vsl_last_error_string", "vsl_version")
 
 
@@ -33,7 +33,7 @@ class LossDesc(ctypes.Structure):
         ("inv_num_scales", ctypes.c_float),
         ("disp", ctypes.c_void_p), ("target", ctypes.c_void_p), ("source", ctypes.c_void_p * MAX_SOURCES),
         ("K", ctypes.c_void_p), ("inv_K", ctypes.c_void_p), ("T", ctypes.c_void_p * MAX_SOURCES),
-        ("noise", ctypes.c_void_p), ("seed", ctypes.c_uint64),
+        ("noise", ctypes.c_void_p), ("seed", ctypes.c_uint64), ("identity_min", ctypes.c_void_p),
     ]
 
 
@@ -56,6 +56,8 @@ def _load():
     lib.vsl_loss_backward.argtypes = [ctypes.POINTER(LossDesc), ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.c_void_p]
+    lib.vsl_identity_min.restype = ctypes.c_int
+    lib.vsl_identity_min.argtypes = [ctypes.POINTER(LossDesc), ctypes.c_void_p, ctypes.c_void_p]
     lib.vsl_last_error_string.restype = ctypes.c_char_p
     lib.vsl_last_error_string.argtypes = []
     lib.vsl_version.restype = ctypes.c_int

@@ -1,27 +1,28 @@
-// Fused view-synthesis-loss tile program (forward + gradient in one pass).
+// Tile programs of the view-synthesis loss (forward + gradient in one pass).
 //
-// One workgroup owns a TW x TH tile of target pixels of one batch element and
-// runs four barrier-separated phases over LDS planes:
+// Ident  -- identity-reprojection error of every un-warped source, plus tie-break noise,
+//           minimum over sources.  Independent of disparity and pose: one launch per batch
+//           serves every disparity head.                    (Trainer.py:553-566,587-590)
 //
-//   phase 1  every position of the tile grown by 2 (region R2): disparity ->
-//            depth -> back-projection -> projection -> bilinear sample of each
-//            source; target / identity-source / warped values go to LDS, the
-//            tap derivatives of the thread's own two interior pixels stay in
-//            registers.                           (layers.py:16-25,161-202, Trainer.py:467)
-//   phase 2a identity-reprojection error of every source on the tile grown by
-//            1 (region R1), plus tie-break noise, running minimum.   (Trainer.py:553-566,587-590)
-//   phase 2b photometric error of every warped source on R1 (3x3 SSIM with
-//            reflection padding + L1), running minimum / argmin, SSIM gradient
-//            coefficients of the winner into LDS.      (layers.py:245-262, Trainer.py:481-495,592-605)
-//   phase 3  interior pixels: 3x3 gather of the coefficients -> dL/dwarped ->
-//            bilinear/projection chain -> dL/ddisp and the 3x4 projection
-//            gradient; edge-aware smoothness terms.    (layers.py:211-226, Trainer.py:609-614)
+// Fused  -- one workgroup owns a TW x TH tile of target pixels of one batch element and runs
+//           barrier-separated phases over LDS planes:
+//   phase 0  projection matrices P = (K T)[:3,:] and inv_K into LDS        (layers.py:189)
+//   phase 1  every position of the tile grown by 2 (region R2): disparity -> depth ->
+//            back-projection -> projection -> bilinear sample of each source; target and
+//            warped values go to LDS, the tap derivatives of the thread's own two interior
+//            pixels stay in registers.          (layers.py:16-25,161-202, Trainer.py:467)
+//   phase 2  photometric error of every warped source on the tile grown by 1 (region R1):
+//            3x3 SSIM with reflection padding + L1, running minimum / argmin against the
+//            identity minimum, SSIM gradient coefficients of the winner into LDS.
+//                                     (layers.py:245-262, Trainer.py:481-495,592-605)
+//   phase 3  interior pixels: 3x3 gather of the coefficients -> dL/dwarped -> bilinear /
+//            projection chain -> dL/ddisp and the 3x4 projection gradient; edge-aware
+//            smoothness terms.                  (layers.py:211-226, Trainer.py:609-614)
 //   phase 4  deterministic block reduction of the partial sums.
 //
-// The phases are plain functions of (thread id, LDS base, per-thread state) so
-// that the same source also compiles as an ordinary C++ program that runs the
-// threads of a block one after the other (used by the CPU test build for
-// address-sanitizer and parity checks; it is not part of the shipped library).
+// The phases are plain functions of (thread id, LDS base, per-thread state) so that the same
+// source also compiles as an ordinary C++ program that runs the threads of a block one after
+// the other (the CPU test build: address-sanitizer and parity checks; not shipped).
 #pragma once
 
 #include <math.h>
@@ -76,6 +77,8 @@ struct KParams {
   const float* T[kMaxSrc];
   const float* noise;
   unsigned long long seed;
+  float* idmin;      // [B,H,W] min over sources of the identity-reprojection error (+ tie-break noise):
+                     // written by the identity tile program, read by the fused one
   float* gphoto;     // [B,H,W] d(photo_w * photo)/d disp
   float* gedge;      // [B,H,W] edge part of the smoothness gradient (before the per-image factors)
   float* ident_sel;  // [B,H,W] or null
@@ -160,11 +163,199 @@ struct Chain {  // what phase 3 needs from phase 1 for one (pixel, source)
 template <int S>
 struct ThreadState {
   Chain ch[2][S];
-  float part[num_partials(S)];
+  float photo;                  // sum of the selected photometric error over this thread's interior pixels
+  float part[num_partials(S)];  // filled at the end of phase 3
 };
 
 // ----------------------------------------------------------------------------
 // tile program
+// ----------------------------------------------------------------------------
+// ----------------------------------------------------------------------------
+// shared window / SSIM helpers (a thread works on two horizontally adjacent pixels)
+// ----------------------------------------------------------------------------
+// 3 rows x 4 columns starting at float offset `base` (even) of an LDS plane
+VSL_DEV void load_win(const float* plane, int base, int pitch, float w[3][4]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float2v a = *reinterpret_cast<const float2v*>(plane + base + r * pitch);
+    const float2v c = *reinterpret_cast<const float2v*>(plane + base + r * pitch + 2);
+    w[r][0] = a.x;
+    w[r][1] = a.y;
+    w[r][2] = c.x;
+    w[r][3] = c.y;
+  }
+}
+
+// left window = columns 0..2, right window = columns 1..3 of per-column sums
+VSL_DEV void two_windows(const float col[4], float out[2]) {
+  const float mid = col[1] + col[2];
+  out[0] = mid + col[0];
+  out[1] = mid + col[3];
+}
+
+// Target-side window sums of both pixels, relative to the common centre yw[1][1].
+// Moments are shift invariant, so any nearby value works as the centre; taking
+// differences first keeps E[y^2] - mu^2 free of cancellation in float32.
+VSL_DEV void y_stats(const float yw[3][4], float sy[2], float syy[2]) {
+  const float cy = yw[1][1];
+  float c1[4], c2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float e0 = yw[0][j] - cy, e1 = yw[1][j] - cy, e2 = yw[2][j] - cy;
+    c1[j] = (e0 + e1) + e2;
+    c2[j] = fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
+  }
+  two_windows(c1, sy);
+  two_windows(c2, syy);
+}
+
+struct SsimOut {
+  float f;        // clamp((1 - SSIM)/2, 0, 1)
+  float A, B, G;  // d f / d x_j = (A + B x_j + G y_j) / 9 for every j of the window
+};
+
+// layers.py:252-262 from centre-relative sums (cx, cy = the common centre values)
+VSL_DEV SsimOut ssim_formula(float cx, float cy, float sx, float sxx, float sxy, float sy, float syy, bool want_coef) {
+  constexpr float i9 = 1.0f / 9.0f;
+  const float mxp = sx * i9, myp = sy * i9;
+  const float mux = cx + mxp, muy = cy + myp;
+  const float vx = fmaf(sxx, i9, -mxp * mxp);
+  const float vy = fmaf(syy, i9, -myp * myp);
+  const float cxy = fmaf(sxy, i9, -mxp * myp);
+  const float n1 = fmaf(2.0f * mux, muy, kC1);
+  const float n2 = fmaf(2.0f, cxy, kC2);
+  const float d1 = fmaf(mux, mux, fmaf(muy, muy, kC1));
+  const float d2 = vx + vy + kC2;
+  const float inv = fast_rcp(d1 * d2);
+  const float val = fmaf(-0.5f * n1, n2 * inv, 0.5f);
+  SsimOut o;
+  o.f = fminf(fmaxf(val, 0.0f), 1.0f);
+  o.A = o.B = o.G = 0.0f;
+  if (want_coef && val >= 0.0f && val <= 1.0f) {  // clamp passes the gradient on [0,1] only
+    const float t = n2 * inv;                     // n2 / (d1 d2)
+    const float inv_d1 = inv * d2, inv_d2 = inv * d1;
+    const float a = -t * (muy - n1 * mux * inv_d1);
+    const float bq = n1 * t * inv_d2;
+    const float g = -n1 * inv;
+    o.A = a - bq * mux - g * muy;
+    o.B = bq;
+    o.G = g;
+  }
+  return o;
+}
+
+// SSIM term of both pixels for one (image, channel)
+VSL_DEV void ssim_pair(const float xw[3][4], const float yw[3][4], const float sy[2], const float syy[2],
+                       bool want_coef, SsimOut out[2]) {
+  const float cx = xw[1][1], cy = yw[1][1];
+  float c1[4], c2[4], c3[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float e0 = xw[0][j] - cx, e1 = xw[1][j] - cx, e2 = xw[2][j] - cx;
+    const float d0 = yw[0][j] - cy, d1 = yw[1][j] - cy, d2 = yw[2][j] - cy;
+    c1[j] = (e0 + e1) + e2;
+    c2[j] = fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
+    c3[j] = fmaf(e2, d2, fmaf(e1, d1, e0 * d0));
+  }
+  float sx[2], sxx[2], sxy[2];
+  two_windows(c1, sx);
+  two_windows(c2, sxx);
+  two_windows(c3, sxy);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) out[k] = ssim_formula(cx, cy, sx[k], sxx[k], sxy[k], sy[k], syy[k], want_coef);
+}
+
+// ----------------------------------------------------------------------------
+// identity tile program: min over sources of the un-warped photometric error
+// (+ tie-break noise), Trainer.py:553-566,587-590.  Independent of disparity and
+// pose, so one launch serves every disparity head of the same batch.
+// ----------------------------------------------------------------------------
+template <int TW, int TH, int NT, int S, bool AVG>
+struct Ident {
+  static constexpr int RW = TW + 2, RH = TH + 2, PN = RW * RH;
+  static constexpr int NPAIR = (TW / 2) * TH;
+  static constexpr int LDS_FLOATS = (3 + 3 * S) * PN;
+  static_assert(NPAIR <= NT && PN % 2 == 0 && TW % 2 == 0, "tile / thread mismatch");
+
+  struct Block {
+    int b, x0, y0;
+  };
+
+  static VSL_DEV void load(const KParams& kp, const Block& bk, int tid, float* lds) {
+    const size_t HW = (size_t)kp.H * kp.W;
+    const size_t img0 = (size_t)bk.b * 3 * HW;
+    for (int p = tid; p < PN; p += NT) {
+      const int ry = p / RW, rx = p % RW;
+      const int py = reflect_clamp(bk.y0 - 1 + ry, kp.H), px = reflect_clamp(bk.x0 - 1 + rx, kp.W);
+      const size_t pix = (size_t)py * kp.W + px;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        lds[c * PN + p] = kp.tgt[img0 + c * HW + pix];
+#pragma unroll
+        for (int s = 0; s < S; ++s) lds[(3 + s * 3 + c) * PN + p] = kp.src[s][img0 + c * HW + pix];
+      }
+    }
+  }
+
+  static VSL_DEV void compute(const KParams& kp, const Block& bk, int tid, const float* lds) {
+    if (tid >= NPAIR) return;
+    const int iy = tid / (TW / 2), ip = tid % (TW / 2);
+    const int gy = bk.y0 + iy, gx0 = bk.x0 + 2 * ip;
+    if (gy >= kp.H || gx0 >= kp.W) return;
+    const int base = iy * RW + 2 * ip;
+    float fsum[S][2], lsum[S][2];
+#pragma unroll
+    for (int s = 0; s < S; ++s) fsum[s][0] = fsum[s][1] = lsum[s][0] = lsum[s][1] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float yw[3][4], sy[2], syy[2];
+      load_win(lds + c * PN, base, RW, yw);
+      if (!kp.no_ssim) y_stats(yw, sy, syy);
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float xw[3][4];
+        load_win(lds + (3 + s * 3 + c) * PN, base, RW, xw);
+        lsum[s][0] += fabsf(yw[1][1] - xw[1][1]);
+        lsum[s][1] += fabsf(yw[1][2] - xw[1][2]);
+        if (!kp.no_ssim) {
+          SsimOut o[2];
+          ssim_pair(xw, yw, sy, syy, false, o);
+          fsum[s][0] += o[0].f;
+          fsum[s][1] += o[1].f;
+        }
+      }
+    }
+    const size_t HW = (size_t)kp.H * kp.W;
+    constexpr int NI = AVG ? 1 : S;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (gx0 + k >= kp.W) continue;
+      const size_t pix = (size_t)gy * kp.W + gx0 + k;
+      float best = INFINITY, idsum = 0.0f;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float e = kp.no_ssim ? lsum[s][k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[s][k], kp.l1_w3 * lsum[s][k]);
+        if (AVG) {
+          idsum += e;
+        } else {
+          const size_t ni = ((size_t)bk.b * NI + s) * HW + pix;
+          const float z = kp.noise ? kp.noise[ni] : hash_normal(kp.seed, ni);
+          const float v = fmaf(z, 0.00001f, e);
+          if (v < best) best = v;
+        }
+      }
+      if (AVG) {
+        const size_t ni = (size_t)bk.b * HW + pix;
+        const float z = kp.noise ? kp.noise[ni] : hash_normal(kp.seed, ni);
+        best = fmaf(z, 0.00001f, idsum * (1.0f / S));
+      }
+      kp.idmin[(size_t)bk.b * HW + pix] = best;
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------
+// fused tile program
 // ----------------------------------------------------------------------------
 template <int TW, int TH, int NT, int S, bool AVG>
 struct Fused {
@@ -180,19 +371,18 @@ struct Fused {
   static_assert(P2 % 2 == 0 && P1 % 2 == 0, "planes must keep 8-byte alignment");
 
   // LDS layout in floats
-  static constexpr int OFF_MAT = 0;                      // 12*S projection entries + 9 inv_K entries
+  static constexpr int OFF_MAT = 0;  // 12*S projection entries + 9 inv_K entries
   static constexpr int MAT_FLOATS = ((12 * S + 9 + 3) / 4) * 4;
-  static constexpr int OFF_TGT = OFF_MAT + MAT_FLOATS;   // 3 planes over R2
-  static constexpr int OFF_WRP = OFF_TGT + 3 * P2;       // S*3 planes over R2
-  static constexpr int OFF_DSP = OFF_WRP + S * 3 * P2;   // 1 plane over R2
-  static constexpr int OFF_U = OFF_DSP + P2;             // union: identity sources | coefficients
-  static constexpr int U_IDENT = S * 3 * P2;
-  static constexpr int U_COEF = (NSET * 9 + 1) * P1;
-  static constexpr int U_SIZE = U_IDENT > U_COEF ? U_IDENT : U_COEF;
+  static constexpr int OFF_TGT = OFF_MAT + MAT_FLOATS;  // 3 planes over R2
+  static constexpr int OFF_WRP = OFF_TGT + 3 * P2;      // S*3 planes over R2
+  static constexpr int OFF_DSP = OFF_WRP + S * 3 * P2;  // 1 plane over R2
+  static constexpr int OFF_COEF = OFF_DSP + P2;         // NSET*9 coefficient planes + selection plane over R1
+  static constexpr int COEF_FLOATS = (NSET * 9 + 1) * P1;
   static constexpr int RED_PITCH = NT + 1;
   static constexpr int RED_FLOATS = NPART * RED_PITCH;
-  static constexpr int LDS_MAIN = OFF_U + U_SIZE;
-  static constexpr int RED_TOTAL = RED_FLOATS + NPART * 8;
+  static constexpr int RED_SPLIT = 8;
+  static constexpr int LDS_MAIN = OFF_COEF + COEF_FLOATS;
+  static constexpr int RED_TOTAL = RED_FLOATS + NPART * RED_SPLIT;
   static constexpr int LDS_FLOATS = LDS_MAIN > RED_TOTAL ? LDS_MAIN : RED_TOTAL;
 
   struct Block {
@@ -213,9 +403,6 @@ struct Fused {
 
   // ---- phase 1: one R2 position --------------------------------------------
   static VSL_DEV void warp_position(const KParams& kp, const Block& bk, int ry, int rx, float* lds, Chain* chain) {
-#if (VSL_NC & 1) && defined(__clang__)
-#pragma clang fp contract(off)
-#endif
     const int H = kp.H, W = kp.W;
     const int py = reflect_clamp(bk.y0 - 2 + ry, H);
     const int px = reflect_clamp(bk.x0 - 2 + rx, W);
@@ -228,12 +415,6 @@ struct Fused {
     lds[OFF_DSP + p2] = d;
 #pragma unroll
     for (int c = 0; c < 3; ++c) lds[OFF_TGT + c * P2 + p2] = kp.tgt[img0 + c * HW + pix];
-    if (kp.automask) {
-#pragma unroll
-      for (int s = 0; s < S; ++s)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) lds[OFF_U + (s * 3 + c) * P2 + p2] = kp.src[s][img0 + c * HW + pix];
-    }
 
     // disp_to_depth and the back-projected ray, layers.py:21-25,163-169
     const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
@@ -290,24 +471,6 @@ struct Fused {
     }
   }
 
-  static VSL_DEV void phase1(const KParams& kp, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
-    for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
-    if (tid < NPAIR0) {
-      const int iy = tid / (TW / 2), ip = tid % (TW / 2);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) warp_position(kp, bk, 2 + iy, 2 + 2 * ip + k, lds, st.ch[k]);
-    }
-    // halo ring of R2: the threads without an interior pair take three positions
-    // each, the remainder goes to the first threads
-    constexpr int EXTRA = NT - NPAIR0;
-    constexpr int NH_A = (3 * EXTRA < NHALO) ? 3 * EXTRA : NHALO;
-    if (tid >= NPAIR0) {
-      for (int h = tid - NPAIR0; h < NH_A; h += EXTRA) halo_item(kp, bk, h, lds);
-    } else {
-      for (int h = NH_A + tid; h < NHALO; h += NPAIR0) halo_item(kp, bk, h, lds);
-    }
-  }
-
   static VSL_DEV void halo_item(const KParams& kp, const Block& bk, int h, float* lds) {
     int ry, rx;
     if (h < 2 * R2W) {  // two top rows
@@ -325,194 +488,64 @@ struct Fused {
     warp_position(kp, bk, ry, rx, lds, nullptr);
   }
 
-  // ---- window helpers ---------------------------------------------------------
-  // 3 rows x 4 columns starting at float offset `base` (even) of a plane with the given pitch
-  static VSL_DEV void load_win(const float* plane, int base, int pitch, float w[3][4]) {
+  static VSL_DEV void phase1(const KParams& kp, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
+    st.photo = 0.0f;
+    if (tid < NPAIR0) {
+      const int iy = tid / (TW / 2), ip = tid % (TW / 2);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const float2v a = *reinterpret_cast<const float2v*>(plane + base + r * pitch);
-      const float2v c = *reinterpret_cast<const float2v*>(plane + base + r * pitch + 2);
-      w[r][0] = a.x;
-      w[r][1] = a.y;
-      w[r][2] = c.x;
-      w[r][3] = c.y;
+      for (int k = 0; k < 2; ++k) warp_position(kp, bk, 2 + iy, 2 + 2 * ip + k, lds, st.ch[k]);
     }
-  }
-  // centred window sums of the target for pixel k of the pair (centre excluded)
-  static VSL_DEV void y_side(const float yw[3][4], int k, float dy[8], float& sy, float& syy) {
-    const float cy = yw[1][1 + k];
-    sy = 0.0f;
-    syy = 0.0f;
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int o = 0; o < 3; ++o) {
-        if (i == 1 && o == 1) continue;
-        const float e = yw[i][k + o] - cy;
-        dy[n++] = e;
-        sy += e;
-        syy = fmaf(e, e, syy);
-      }
-  }
-
-  struct SsimOut {
-    float f;        // clamp((1 - SSIM)/2, 0, 1)
-    float A, B, G;  // d f / d x_j = (A + B x_j + G y_j) / 9 for j in the window
-  };
-
-  // layers.py:252-262 on shift-invariant (window-centre-relative) moments
-  static VSL_DEV SsimOut ssim_pixel(const float xw[3][4], int k, const float dy[8], float cy, float sy, float syy,
-                                    bool want_coef) {
-#if (VSL_NC & 2) && defined(__clang__)
-#pragma clang fp contract(off)
-#endif
-    const float cx = xw[1][1 + k];
-    float sx = 0.0f, sxx = 0.0f, sxy = 0.0f;
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int o = 0; o < 3; ++o) {
-        if (i == 1 && o == 1) continue;
-        const float e = xw[i][k + o] - cx;
-        sx += e;
-        sxx = fmaf(e, e, sxx);
-        sxy = fmaf(e, dy[n++], sxy);
-      }
-    constexpr float i9 = 1.0f / 9.0f;
-    const float mxp = sx * i9, myp = sy * i9;
-    const float mux = cx + mxp, muy = cy + myp;
-    const float vx = fmaf(sxx, i9, -mxp * mxp);
-    const float vy = fmaf(syy, i9, -myp * myp);
-    const float cxy = fmaf(sxy, i9, -mxp * myp);
-    const float n1 = fmaf(2.0f * mux, muy, kC1);
-    const float n2 = fmaf(2.0f, cxy, kC2);
-    const float d1 = fmaf(mux, mux, fmaf(muy, muy, kC1));
-    const float d2 = vx + vy + kC2;
-    const float inv = fast_rcp(d1 * d2);
-    const float val = fmaf(-0.5f * n1, n2 * inv, 0.5f);
-    SsimOut o;
-    o.f = fminf(fmaxf(val, 0.0f), 1.0f);
-    o.A = o.B = o.G = 0.0f;
-    if (want_coef && val >= 0.0f && val <= 1.0f) {
-      const float t = n2 * inv;              // n2 / (d1 d2)
-      const float inv_d1 = inv * d2, inv_d2 = inv * d1;
-      const float a = -t * (muy - n1 * mux * inv_d1);
-      const float bq = n1 * t * inv_d2;
-      const float g = -n1 * inv;
-      o.A = a - bq * mux - g * muy;
-      o.B = bq;
-      o.G = g;
-    }
-    return o;
-  }
-
-  struct PairPos {
-    int qy, qx0;       // R1 coordinates of the left pixel of the pair
-    int gy, gx[2];     // image coordinates
-    bool valid[2];     // inside the image
-    bool interior[2];  // inside the tile proper (and the image)
-  };
-
-  static VSL_DEV PairPos pair1(const KParams& kp, const Block& bk, int item) {
-    PairPos p;
-    p.qy = item / (R1W / 2);
-    p.qx0 = 2 * (item % (R1W / 2));
-    p.gy = bk.y0 - 1 + p.qy;
-    const bool rowv = p.gy >= 0 && p.gy < kp.H;
-    const bool rowi = p.qy >= 1 && p.qy <= TH;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      p.gx[k] = bk.x0 - 1 + p.qx0 + k;
-      p.valid[k] = rowv && p.gx[k] >= 0 && p.gx[k] < kp.W;
-      p.interior[k] = p.valid[k] && rowi && (p.qx0 + k) >= 1 && (p.qx0 + k) <= TW;
-    }
-    return p;
-  }
-
-  // per-thread carry between phase 2a and 2b (kept in registers / ThreadState is not needed
-  // because both run in the same function on the device; the host build calls them back to back
-  // per thread as well, with a block-wide barrier in between, so the carry lives in `Min2`)
-  struct Min2 {
-    float best[2];
-    float idsum[2];  // AVG: running sum of identity errors
-  };
-
-  // ---- phase 2a: identity reprojection -----------------------------------------
-  static VSL_DEV void phase2a(const KParams& kp, const Block& bk, int tid, const float* lds, Min2& mn) {
-    mn.best[0] = mn.best[1] = INFINITY;
-    mn.idsum[0] = mn.idsum[1] = 0.0f;
-    if (!kp.automask || tid >= NPAIR1) return;
-    const PairPos pp = pair1(kp, bk, tid);
-    const int base = pp.qy * R2W + pp.qx0;
-    float fsum[S][2], lsum[S][2];
-#pragma unroll
-    for (int s = 0; s < S; ++s) fsum[s][0] = fsum[s][1] = lsum[s][0] = lsum[s][1] = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float yw[3][4];
-      load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
-      float dy[2][8], sy[2], syy[2];
-      if (!kp.no_ssim) {
-        y_side(yw, 0, dy[0], sy[0], syy[0]);
-        y_side(yw, 1, dy[1], sy[1], syy[1]);
-      }
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        float xw[3][4];
-        load_win(lds + OFF_U + (s * 3 + c) * P2, base, R2W, xw);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          lsum[s][k] += fabsf(yw[1][1 + k] - xw[1][1 + k]);
-          if (!kp.no_ssim) fsum[s][k] += ssim_pixel(xw, k, dy[k], yw[1][1 + k], sy[k], syy[k], false).f;
-        }
-      }
-    }
-    const size_t HW = (size_t)kp.H * kp.W;
-    constexpr int NI = AVG ? 1 : S;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (!pp.valid[k]) continue;
-      const size_t pix = (size_t)pp.gy * kp.W + pp.gx[k];
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const float e = kp.no_ssim ? lsum[s][k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[s][k], kp.l1_w3 * lsum[s][k]);
-        if (AVG) {
-          mn.idsum[k] += e;
-        } else {
-          const size_t ni = ((size_t)bk.b * NI + s) * HW + pix;
-          const float z = kp.noise ? kp.noise[ni] : hash_normal(kp.seed, ni);
-          const float v = e + z * 0.00001f;
-          if (v < mn.best[k]) mn.best[k] = v;
-        }
-      }
-      if (AVG) {
-        const size_t ni = (size_t)bk.b * HW + pix;
-        const float z = kp.noise ? kp.noise[ni] : hash_normal(kp.seed, ni);
-        mn.best[k] = mn.idsum[k] * (1.0f / S) + z * 0.00001f;
-      }
+    // halo ring of R2: the threads without an interior pair take three positions
+    // each, the remainder goes to the first threads
+    constexpr int EXTRA = NT - NPAIR0;
+    constexpr int NH_A = (3 * EXTRA < NHALO) ? 3 * EXTRA : NHALO;
+    if (tid >= NPAIR0) {
+      for (int h = tid - NPAIR0; h < NH_A; h += EXTRA) halo_item(kp, bk, h, lds);
+    } else {
+      for (int h = NH_A + tid; h < NHALO; h += NPAIR0) halo_item(kp, bk, h, lds);
     }
   }
 
-  // ---- phase 2b: warped sources, running argmin, coefficients -----------------
-  static VSL_DEV void phase2b(const KParams& kp, const Block& bk, int tid, float* lds, const Min2& mn,
-                              ThreadState<S>& st) {
-#if (VSL_NC & 8) && defined(__clang__)
-#pragma clang fp contract(off)
-#endif
+  // ---- phase 2: photometric error on R1, running argmin, coefficients -----------
+  static VSL_DEV void phase2(const KParams& kp, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
     if (tid >= NPAIR1) return;
-    const PairPos pp = pair1(kp, bk, tid);
-    const int base = pp.qy * R2W + pp.qx0;
-    const int q1 = pp.qy * R1W + pp.qx0;
-    float* coef = lds + OFF_U;            // [NSET][9][P1]
-    float* sel = lds + OFF_U + NSET * 9 * P1;  // [P1] winner (source index, -1 = none) / AVG: 1 = warped wins
-    float best[2] = {mn.best[0], mn.best[1]};
+    const int qy = tid / (R1W / 2), qx0 = 2 * (tid % (R1W / 2));
+    const int gy = bk.y0 - 1 + qy, gx0 = bk.x0 - 1 + qx0;
+    const bool rowv = gy >= 0 && gy < kp.H;
+    const bool rowi = qy >= 1 && qy <= TH;
+    bool valid[2], interior[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      valid[k] = rowv && gx0 + k >= 0 && gx0 + k < kp.W;
+      interior[k] = valid[k] && rowi && (qx0 + k) >= 1 && (qx0 + k) <= TW;
+    }
+    const int base = qy * R2W + qx0;
+    const int q1 = qy * R1W + qx0;
+    float* coef = lds + OFF_COEF;               // [NSET][9][P1]
+    float* sel = lds + OFF_COEF + NSET * 9 * P1;  // [P1] winning source (-1 = none); AVG: 1 = warped wins
+
+    const size_t HW = (size_t)kp.H * kp.W;
+    float best[2] = {INFINITY, INFINITY};
+    if (kp.automask) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (valid[k]) best[k] = kp.idmin[(size_t)bk.b * HW + (size_t)gy * kp.W + gx0 + k];
+    }
     float win[2] = {-1.0f, -1.0f};
     float rsum[2] = {0.0f, 0.0f};
     if (!AVG) {
 #pragma unroll
       for (int e = 0; e < 9; ++e) *reinterpret_cast<float2v*>(coef + e * P1 + q1) = float2v{0.0f, 0.0f};
+    }
+    // target-side window sums once per channel
+    float sy[3][2], syy[3][2];
+    if (!kp.no_ssim) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float yw[3][4];
+        load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
+        y_stats(yw, sy[c], syy[c]);
+      }
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -523,19 +556,18 @@ struct Fused {
         float yw[3][4], xw[3][4];
         load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
         load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
+        lsum[0] += fabsf(yw[1][1] - xw[1][1]);
+        lsum[1] += fabsf(yw[1][2] - xw[1][2]);
+        SsimOut o[2];
+        o[0].f = o[1].f = 0.0f;
+        o[0].A = o[0].B = o[0].G = o[1].A = o[1].B = o[1].G = 0.0f;
+        if (!kp.no_ssim) ssim_pair(xw, yw, sy[c], syy[c], kp.want_grad != 0, o);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          lsum[k] += fabsf(yw[1][1 + k] - xw[1][1 + k]);
-          cf[k][c * 3 + 0] = cf[k][c * 3 + 1] = cf[k][c * 3 + 2] = 0.0f;
-          if (!kp.no_ssim) {
-            float dy[8], sy, syy;
-            y_side(yw, k, dy, sy, syy);
-            const SsimOut o = ssim_pixel(xw, k, dy, yw[1][1 + k], sy, syy, kp.want_grad != 0);
-            fsum[k] += o.f;
-            cf[k][c * 3 + 0] = o.A;
-            cf[k][c * 3 + 1] = o.B;
-            cf[k][c * 3 + 2] = o.G;
-          }
+          fsum[k] += o[k].f;
+          cf[k][c * 3 + 0] = o[k].A;
+          cf[k][c * 3 + 1] = o[k].B;
+          cf[k][c * 3 + 2] = o[k].G;
         }
       }
 #pragma unroll
@@ -545,8 +577,8 @@ struct Fused {
         if (AVG) {
           rsum[k] += e;
 #pragma unroll
-          for (int j = 0; j < 9; ++j) coef[(s * 9 + j) * P1 + q1 + k] = pp.valid[k] ? cf[k][j] : 0.0f;
-        } else if (pp.valid[k] && e < best[k]) {
+          for (int j = 0; j < 9; ++j) coef[(s * 9 + j) * P1 + q1 + k] = valid[k] ? cf[k][j] : 0.0f;
+        } else if (valid[k] && e < best[k]) {
           best[k] = e;
           win[k] = (float)s;
 #pragma unroll
@@ -558,26 +590,25 @@ struct Fused {
     for (int k = 0; k < 2; ++k) {
       if (AVG) {
         const float e = rsum[k] * (1.0f / S);
-        win[k] = -1.0f;
-        if (pp.valid[k] && e < best[k]) {
+        if (valid[k] && e < best[k]) {
           best[k] = e;
           win[k] = 1.0f;
         }
       }
       sel[q1 + k] = win[k];
-      if (pp.interior[k]) {
-        st.part[0] += best[k];
+      if (interior[k]) {
+        st.photo += best[k];
         if (kp.automask && kp.ident_sel)
-          kp.ident_sel[((size_t)bk.b * kp.H + pp.gy) * kp.W + pp.gx[k]] = (win[k] >= 0.0f) ? 1.0f : 0.0f;
+          kp.ident_sel[((size_t)bk.b * kp.H + gy) * kp.W + gx0 + k] = (win[k] >= 0.0f) ? 1.0f : 0.0f;
       }
     }
   }
 
   // ---- phase 3: gradients of the interior pair ---------------------------------
   static VSL_DEV void phase3(const KParams& kp, const Block& bk, int tid, const float* lds, ThreadState<S>& st) {
-#if (VSL_NC & 4) && defined(__clang__)
-#pragma clang fp contract(off)
-#endif
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
+    st.part[0] = st.photo;
     if (tid >= NPAIR0) return;
     const int H = kp.H, W = kp.W;
     const int iy = tid / (TW / 2), ip = tid % (TW / 2);
@@ -586,121 +617,121 @@ struct Fused {
     const int jx0 = bk.x0 + 2 * ip;
     if (jx0 >= W) return;
     const bool ok[2] = {true, jx0 + 1 < W};
-    const float* coef = lds + OFF_U;
-    const float* sel = lds + OFF_U + NSET * 9 * P1;
+    const float* coef = lds + OFF_COEF;
+    const float* sel = lds + OFF_COEF + NSET * 9 * P1;
     const int qb = iy * R1W + 2 * ip;  // R1 offset of the window's top-left (even)
+    const int p2 = (2 + iy) * R2W + 2 + 2 * ip;
     const size_t HW = (size_t)H * W;
 
     float g_disp[2] = {0.0f, 0.0f};
     if (kp.want_grad) {
-      // reflection-padding fold: a window on the image border counts twice for the
-      // pixel next to the border (layers.py:240,249-250 backward)
-      float fy[3], fxm[2][3];
+      // Reflection-padding fold (backward of layers.py:240,249-250): a window centred on the image
+      // border counts twice for the pixel next to the border.  Only tiles that contain column 1 /
+      // W-2 or row 1 / H-2 need the weights; the test is uniform over the workgroup.
+      const bool border = bk.x0 == 0 || bk.y0 == 0 || (bk.x0 <= W - 2 && W - 2 < bk.x0 + TW) ||
+                          (bk.y0 <= H - 2 && H - 2 < bk.y0 + TH);
+      float fy[3] = {1.0f, 1.0f, 1.0f}, fxm[2][3] = {{1.0f, 1.0f, 1.0f}, {1.0f, 1.0f, 1.0f}};
+      if (border) {
+        fy[0] += (float)(jy == 1);
+        fy[2] += (float)(jy == H - 2);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) fy[i] = 1.0f + (float)(jy == 1 && i == 0) + (float)(jy == H - 2 && i == 2);
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int o = 0; o < 3; ++o)
-          fxm[k][o] = 1.0f + (float)(jx0 + k == 1 && o == 0) + (float)(jx0 + k == W - 2 && o == 2);
-
-      float selw[3][4];
-      load_win(sel, qb, R1W, selw);
-      float acc[S][2][9];
-#pragma unroll
-      for (int s = 0; s < S; ++s)
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-          for (int j = 0; j < 9; ++j) acc[s][k][j] = 0.0f;
-
-      if (!kp.no_ssim) {
-        if (AVG) {
-#pragma unroll
-          for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-              float cw[3][4];
-              load_win(coef + (s * 9 + j) * P1, qb, R1W, cw);
-#pragma unroll
-              for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                  for (int o = 0; o < 3; ++o) {
-                    const float m = (selw[i][k + o] > 0.0f) ? fy[i] * fxm[k][o] : 0.0f;
-                    acc[s][k][j] = fmaf(m, cw[i][k + o], acc[s][k][j]);
-                  }
-            }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 9; ++j) {
-            float cw[3][4];
-            load_win(coef + j * P1, qb, R1W, cw);
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-#pragma unroll
-              for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                  for (int o = 0; o < 3; ++o) {
-                    const float m = (selw[i][k + o] == (float)s) ? fy[i] * fxm[k][o] : 0.0f;
-                    acc[s][k][j] = fmaf(m, cw[i][k + o], acc[s][k][j]);
-                  }
-          }
+        for (int k = 0; k < 2; ++k) {
+          fxm[k][0] += (float)(jx0 + k == 1);
+          fxm[k][2] += (float)(jx0 + k == W - 2);
         }
       }
-
+      float selw[3][4];
+      load_win(sel, qb, R1W, selw);
       const float* ikm = lds + OFF_MAT + 12 * S;
       const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+
+      float D[2], r[2][3];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        if (!ok[k]) continue;
-        const int p2 = (2 + iy) * R2W + 2 + 2 * ip + k;
-        const float d = lds[OFF_DSP + p2];
+        const float d = lds[OFF_DSP + p2 + k];
         const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
-        const float D = VSL_FDIV(1.0f, sd);
+        D[k] = VSL_FDIV(1.0f, sd);
         const float fx = (float)(jx0 + k), fyv = (float)jy;
-        float r[3], Xh[4];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          r[i] = fmaf(ikm[i * 3 + 2], 1.0f, fmaf(ikm[i * 3 + 1], fyv, ikm[i * 3 + 0] * fx));
-          Xh[i] = D * r[i];
-        }
-        Xh[3] = 1.0f;
-        const float selj = selw[1][1 + k];
-        float gD = 0.0f;
+        for (int i = 0; i < 3; ++i) r[k][i] = fmaf(ikm[i * 3 + 2], 1.0f, fmaf(ikm[i * 3 + 1], fyv, ikm[i * 3 + 0] * fx));
+      }
+      float gD[2] = {0.0f, 0.0f};
+
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-          const float picked = AVG ? (float)(selj > 0.0f) : (float)(selj == (float)s);
-          float gix = 0.0f, giy = 0.0f;
+      for (int s = 0; s < S; ++s) {
+        // 0/1 mask of the window positions whose winner is source s
+        float msk[3][4];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float x = lds[OFF_WRP + (s * 3 + c) * P2 + p2];
-            const float y = lds[OFF_TGT + c * P2 + p2];
-            float g = kp.cst_ssim * (acc[s][k][c * 3 + 0] + acc[s][k][c * 3 + 1] * x + acc[s][k][c * 3 + 2] * y);
-            g -= kp.cst_l1 * picked * sgn(y - x);
-            gix = fmaf(g, st.ch[k][s].dpx[c], gix);
-            giy = fmaf(g, st.ch[k][s].dpy[c], giy);
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) msk[i][j] = AVG ? (float)(selw[i][j] > 0.0f) : (float)(selw[i][j] == (float)s);
+        float gix[2] = {0.0f, 0.0f}, giy[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float acc[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+          if (!kp.no_ssim) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              float cw[3][4];
+              load_win(coef + ((AVG ? s * 9 : 0) + c * 3 + e) * P1, qb, R1W, cw);
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cw[i][j] *= msk[i][j];
+              if (!border) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                  const float mid = cw[i][1] + cw[i][2];
+                  acc[0][e] += mid + cw[i][0];
+                  acc[1][e] += mid + cw[i][3];
+                }
+              } else {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                  for (int i = 0; i < 3; ++i) {
+                    const float row = fmaf(fxm[k][0], cw[i][k], fmaf(fxm[k][2], cw[i][k + 2], cw[i][k + 1]));
+                    acc[k][e] = fmaf(fy[i], row, acc[k][e]);
+                  }
+              }
+            }
           }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float x = lds[OFF_WRP + (s * 3 + c) * P2 + p2 + k];
+            const float y = lds[OFF_TGT + c * P2 + p2 + k];
+            const float selj = selw[1][1 + k];
+            const float picked = AVG ? (float)(selj > 0.0f) : (float)(selj == (float)s);
+            float g = kp.cst_ssim * (acc[k][0] + acc[k][1] * x + acc[k][2] * y);
+            g -= kp.cst_l1 * picked * sgn(y - x);
+            gix[k] = fmaf(g, st.ch[k][s].dpx[c], gix[k]);
+            giy[k] = fmaf(g, st.ch[k][s].dpy[c], giy[k]);
+          }
+        }
+        const float* P = lds + OFF_MAT + 12 * s;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (!ok[k]) continue;
           // d ix / d gx = W/2, d gx / d u = 2/(W-1)
-          const float gu = gix * ((float)W / wm1), gv = giy * ((float)H / hm1);
+          const float gu = gix[k] * ((float)W / wm1), gv = giy[k] * ((float)H / hm1);
           const float id = st.ch[k][s].inv_den;
           const float gc[3] = {gu * id, gv * id, -(gu * st.ch[k][s].u + gv * st.ch[k][s].v) * id};
-          const float* P = lds + OFF_MAT + 12 * s;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             const float gX = P[0 * 4 + i] * gc[0] + P[1 * 4 + i] * gc[1] + P[2 * 4 + i] * gc[2];
-            gD = fmaf(gX, r[i], gD);
+            gD[k] = fmaf(gX, r[k][i], gD[k]);
           }
 #pragma unroll
-          for (int i = 0; i < 3; ++i)
+          for (int i = 0; i < 3; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) st.part[4 + 12 * s + i * 4 + j] = fmaf(gc[i], Xh[j], st.part[4 + 12 * s + i * 4 + j]);
+            for (int j = 0; j < 3; ++j)
+              st.part[4 + 12 * s + i * 4 + j] = fmaf(gc[i] * D[k], r[k][j], st.part[4 + 12 * s + i * 4 + j]);
+            st.part[4 + 12 * s + i * 4 + 3] += gc[i];
+          }
         }
-        g_disp[k] = gD * (-kp.c_disp * D * D);
       }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) g_disp[k] = gD[k] * (-kp.c_disp * D[k] * D[k]);
     }
 
     // edge-aware smoothness, layers.py:211-226 with the 1/(mean+1e-7) factor applied later
@@ -708,20 +739,20 @@ struct Fused {
     for (int k = 0; k < 2; ++k) {
       if (!ok[k]) continue;
       const int jx = jx0 + k;
-      const int p2 = (2 + iy) * R2W + 2 + 2 * ip + k;
-      const float d0 = lds[OFF_DSP + p2];
-      float ax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // mean_c |I - I_neighbour| for right, left, down, up
+      const int pp = p2 + k;
+      const float d0 = lds[OFF_DSP + pp];
+      float ax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum_c |I - I_neighbour| for right, left, down, up
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float* tp = lds + OFF_TGT + c * P2;
-        const float i0 = tp[p2];
-        ax[0] += fabsf(i0 - tp[p2 + 1]);
-        ax[1] += fabsf(tp[p2 - 1] - i0);
-        ax[2] += fabsf(i0 - tp[p2 + R2W]);
-        ax[3] += fabsf(tp[p2 - R2W] - i0);
+        const float i0 = tp[pp];
+        ax[0] += fabsf(i0 - tp[pp + 1]);
+        ax[1] += fabsf(tp[pp - 1] - i0);
+        ax[2] += fabsf(i0 - tp[pp + R2W]);
+        ax[3] += fabsf(tp[pp - R2W] - i0);
       }
-      const float dn[4] = {lds[OFF_DSP + p2 + 1], lds[OFF_DSP + p2 - 1], lds[OFF_DSP + p2 + R2W],
-                           lds[OFF_DSP + p2 - R2W]};
+      const float dn[4] = {lds[OFF_DSP + pp + 1], lds[OFF_DSP + pp - 1], lds[OFF_DSP + pp + R2W],
+                           lds[OFF_DSP + pp - R2W]};
       const bool has[4] = {jx + 1 < W, jx > 0, jy + 1 < H, jy > 0};
       float e = 0.0f;
 #pragma unroll
@@ -746,7 +777,6 @@ struct Fused {
   }
 
   // ---- phase 4: deterministic block reduction ----------------------------------
-  static constexpr int RED_SPLIT = 8;
   static VSL_DEV void phase4_store(int tid, float* lds, const ThreadState<S>& st) {
 #pragma unroll
     for (int k = 0; k < NPART; ++k) lds[k * RED_PITCH + tid] = st.part[k];

@@ -1,5 +1,6 @@
 // libvsloss.so -- kernels and C-ABI entry points of the fused view-synthesis loss.
 //
+//   vsl_ident_kernel     identity-reprojection minimum per pixel (once per batch)
 //   vsl_fused_kernel     one workgroup per 32x16 tile; the tile program of vsl_fused.hpp
 //   vsl_finalize_kernel  one workgroup per image: deterministic float64 reduction of the
 //                        tile records, per-image smoothness factors, pose gradients; the
@@ -30,7 +31,7 @@ int fail(int code, const std::string& msg) {
 // fused tile kernel
 // --------------------------------------------------------------------------
 template <int S, bool AVG>
-__global__ __launch_bounds__(kNT) void vsl_fused_kernel(const KParams kp) {
+__global__ __launch_bounds__(kNT, (S <= 2 ? 4 : 3)) void vsl_fused_kernel(const KParams kp) {
   using F = Fused<kTW, kTH, kNT, S, AVG>;
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x;
@@ -41,14 +42,11 @@ __global__ __launch_bounds__(kNT) void vsl_fused_kernel(const KParams kp) {
   const int block_linear = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 
   ThreadState<S> st;
-  typename F::Min2 mn;
   F::phase0(kp, bk, tid, lds);
   __syncthreads();
   F::phase1(kp, bk, tid, lds, st);
   __syncthreads();
-  F::phase2a(kp, bk, tid, lds, mn);
-  __syncthreads();
-  F::phase2b(kp, bk, tid, lds, mn, st);
+  F::phase2(kp, bk, tid, lds, st);
   __syncthreads();
   F::phase3(kp, bk, tid, lds, st);
   __syncthreads();
@@ -57,6 +55,22 @@ __global__ __launch_bounds__(kNT) void vsl_fused_kernel(const KParams kp) {
   F::phase4_sum_a(tid, lds);
   __syncthreads();
   F::phase4_sum_b(kp, block_linear, tid, lds);
+}
+
+// --------------------------------------------------------------------------
+// identity minimum
+// --------------------------------------------------------------------------
+template <int S, bool AVG>
+__global__ __launch_bounds__(kNT) void vsl_ident_kernel(const KParams kp) {
+  using I = Ident<kTW, kTH, kNT, S, AVG>;
+  __shared__ __align__(16) float lds[I::LDS_FLOATS];
+  typename I::Block bk;
+  bk.b = blockIdx.z;
+  bk.x0 = blockIdx.x * kTW;
+  bk.y0 = blockIdx.y * kTH;
+  I::load(kp, bk, threadIdx.x, lds);
+  __syncthreads();
+  I::compute(kp, bk, threadIdx.x, lds);
 }
 
 // --------------------------------------------------------------------------
@@ -189,7 +203,7 @@ inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 struct Layout {
   int tiles_x, tiles_y, tiles_per_image, blocks;
-  size_t off_partials, off_gphoto, off_gedge, off_img, off_gT, off_c12, off_counter, total;
+  size_t off_partials, off_gphoto, off_gedge, off_idmin, off_img, off_gT, off_c12, off_counter, total;
 };
 
 Layout make_layout(int B, int H, int W) {
@@ -206,6 +220,8 @@ Layout make_layout(int B, int H, int W) {
   L.off_gphoto = o;
   o += align256((size_t)B * H * W * sizeof(float));
   L.off_gedge = o;
+  o += align256((size_t)B * H * W * sizeof(float));
+  L.off_idmin = o;
   o += align256((size_t)B * H * W * sizeof(float));
   L.off_img = o;
   o += align256((size_t)B * 4 * sizeof(double));
@@ -255,6 +271,46 @@ int launch_fused_s(const KParams& kp, bool avg, dim3 grid, hipStream_t stream) {
   return avg ? launch_fused<S, true>(kp, grid, stream) : launch_fused<S, false>(kp, grid, stream);
 }
 
+template <int S>
+void launch_ident_s(const KParams& kp, bool avg, dim3 grid, hipStream_t stream) {
+  if (avg)
+    hipLaunchKernelGGL((vsl_ident_kernel<S, true>), grid, dim3(kNT), 0, stream, kp);
+  else
+    hipLaunchKernelGGL((vsl_ident_kernel<S, false>), grid, dim3(kNT), 0, stream, kp);
+}
+
+void launch_ident(const KParams& kp, bool avg, dim3 grid, hipStream_t stream) {
+  switch (kp.S) {
+    case 1: launch_ident_s<1>(kp, avg, grid, stream); break;
+    case 2: launch_ident_s<2>(kp, avg, grid, stream); break;
+    case 3: launch_ident_s<3>(kp, avg, grid, stream); break;
+    default: launch_ident_s<4>(kp, avg, grid, stream); break;
+  }
+}
+
+// the part of the kernel parameters that only depends on the descriptor
+KParams base_params(const vsl_loss_desc* d) {
+  KParams kp{};
+  kp.B = d->B;
+  kp.H = d->H;
+  kp.W = d->W;
+  kp.S = d->S;
+  kp.automask = (d->flags & VSL_FLAG_AUTOMASK) != 0;
+  kp.no_ssim = (d->flags & VSL_FLAG_NO_SSIM) != 0;
+  kp.eps = d->eps;
+  kp.ssim_w3 = d->ssim_weight / 3.0f;
+  kp.l1_w3 = d->l1_weight / 3.0f;
+  kp.warp_scale = d->warp_scale;
+  kp.tgt = d->target;
+  for (int s = 0; s < kMaxSrc; ++s) {
+    kp.src[s] = s < d->S ? d->source[s] : nullptr;
+    kp.T[s] = s < d->S ? d->T[s] : nullptr;
+  }
+  kp.noise = d->noise;
+  kp.seed = d->seed;
+  return kp;
+}
+
 }  // namespace
 
 extern "C" {
@@ -289,35 +345,18 @@ int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_b
   const float smooth_w = smooth_sum * d->inv_num_scales;
   const double npix = (double)d->B * d->H * d->W;
 
-  KParams kp{};
-  kp.B = d->B;
-  kp.H = d->H;
-  kp.W = d->W;
-  kp.S = d->S;
-  kp.automask = automask;
-  kp.no_ssim = no_ssim;
+  KParams kp = base_params(d);
   // python floats: min_disp = 1/max_depth, (max_disp - min_disp), then cast to float32 (layers.py:21-23)
   kp.a_disp = (float)(1.0 / (double)d->max_depth);
   kp.c_disp = (float)(1.0 / (double)d->min_depth - 1.0 / (double)d->max_depth);
-  kp.eps = d->eps;
   const double base = (double)d->warp_scale * photo_w / npix / (avg ? (double)d->S : 1.0);
   kp.cst_ssim = no_ssim ? 0.0f : (float)(base * d->ssim_weight / 27.0);
   kp.cst_l1 = no_ssim ? (float)(base / 3.0) : (float)(base * d->l1_weight / 3.0);
-  kp.ssim_w3 = d->ssim_weight / 3.0f;
-  kp.l1_w3 = d->l1_weight / 3.0f;
-  kp.warp_scale = d->warp_scale;
   kp.inv_nx = (float)(1.0 / ((double)d->B * d->H * (d->W - 1)));
   kp.inv_ny = (float)(1.0 / ((double)d->B * (d->H - 1) * d->W));
   kp.disp = d->disp;
-  kp.tgt = d->target;
   kp.K = d->K;
   kp.invK = d->inv_K;
-  for (int s = 0; s < kMaxSrc; ++s) {
-    kp.src[s] = s < d->S ? d->source[s] : nullptr;
-    kp.T[s] = s < d->S ? d->T[s] : nullptr;
-  }
-  kp.noise = d->noise;
-  kp.seed = d->seed;
   kp.gphoto = (float*)(ws + L.off_gphoto);
   kp.gedge = (float*)(ws + L.off_gedge);
   kp.ident_sel = identity_selection;
@@ -326,6 +365,14 @@ int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_b
   kp.counter = (unsigned int*)(ws + L.off_counter);
 
   const dim3 grid(L.tiles_x, L.tiles_y, d->B);
+  if (automask) {
+    if (d->identity_min) {
+      kp.idmin = const_cast<float*>(d->identity_min);
+    } else {
+      kp.idmin = (float*)(ws + L.off_idmin);
+      launch_ident(kp, avg, grid, stream);
+    }
+  }
   int rc = VSL_OK;
   switch (d->S) {
     case 1: rc = launch_fused_s<1>(kp, avg, grid, stream); break;
@@ -355,6 +402,22 @@ int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_b
   fp.counter = (unsigned int*)(ws + L.off_counter);
   fp.losses = losses;
   hipLaunchKernelGGL(vsl_finalize_kernel, dim3(d->B), dim3(256), 0, stream, fp);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess)
+    return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  return VSL_OK;
+}
+
+int vsl_identity_min(const vsl_loss_desc* d, float* identity_min, void* stream_) {
+  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
+  if (d->B < 1 || d->B > 65535 || d->H < 2 || d->W < 2) return fail(VSL_ERR_INVALID_ARGUMENT, "need 1 <= B <= 65535, H >= 2, W >= 2");
+  if (d->S < 1 || d->S > VSL_MAX_SOURCES) return fail(VSL_ERR_INVALID_ARGUMENT, "S must be 1..VSL_MAX_SOURCES");
+  if (!d->target || !identity_min) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL tensor");
+  for (int s = 0; s < d->S; ++s)
+    if (!d->source[s]) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL source image");
+  KParams kp = base_params(d);
+  kp.idmin = identity_min;
+  const Layout L = make_layout(d->B, d->H, d->W);
+  launch_ident(kp, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0, dim3(L.tiles_x, L.tiles_y, d->B), (hipStream_t)stream_);
   if (hipError_t e = hipGetLastError(); e != hipSuccess)
     return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return VSL_OK;

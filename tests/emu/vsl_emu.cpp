@@ -16,12 +16,27 @@ namespace {
 constexpr int kTW = 32, kTH = 16, kNT = 320;
 
 template <int S, bool AVG>
+void run_ident(const KParams& kp) {
+  using I = Ident<kTW, kTH, kNT, S, AVG>;
+  const int tx = (kp.W + kTW - 1) / kTW, ty = (kp.H + kTH - 1) / kTH;
+  std::vector<float> lds(I::LDS_FLOATS);
+  for (int b = 0; b < kp.B; ++b)
+    for (int by = 0; by < ty; ++by)
+      for (int bx = 0; bx < tx; ++bx) {
+        typename I::Block bk{b, bx * kTW, by * kTH};
+        for (auto& v : lds) v = NAN;
+        for (int t = 0; t < kNT; ++t) I::load(kp, bk, t, lds.data());
+        for (int t = 0; t < kNT; ++t) I::compute(kp, bk, t, lds.data());
+      }
+}
+
+template <int S, bool AVG>
 void run_tiles(KParams kp) {
   using F = Fused<kTW, kTH, kNT, S, AVG>;
+  if (kp.automask) run_ident<S, AVG>(kp);
   const int tx = (kp.W + kTW - 1) / kTW, ty = (kp.H + kTH - 1) / kTH;
   std::vector<float> lds(F::LDS_FLOATS);
   std::vector<ThreadState<S>> st(kNT);
-  std::vector<typename F::Min2> mn(kNT);
   for (int b = 0; b < kp.B; ++b)
     for (int by = 0; by < ty; ++by)
       for (int bx = 0; bx < tx; ++bx) {
@@ -31,8 +46,7 @@ void run_tiles(KParams kp) {
         for (auto& v : lds) v = NAN;
         for (int t = 0; t < kNT; ++t) F::phase0(kp, bk, t, lds.data());
         for (int t = 0; t < kNT; ++t) F::phase1(kp, bk, t, lds.data(), st[t]);
-        for (int t = 0; t < kNT; ++t) F::phase2a(kp, bk, t, lds.data(), mn[t]);
-        for (int t = 0; t < kNT; ++t) F::phase2b(kp, bk, t, lds.data(), mn[t], st[t]);
+        for (int t = 0; t < kNT; ++t) F::phase2(kp, bk, t, lds.data(), st[t]);
         for (int t = 0; t < kNT; ++t) F::phase3(kp, bk, t, lds.data(), st[t]);
         for (int t = 0; t < kNT; ++t) F::phase4_store(t, lds.data(), st[t]);
         for (int t = 0; t < kNT; ++t) F::phase4_sum_a(t, lds.data());

@@ -36,7 +36,7 @@ class KParams(ctypes.Structure):
         ("inv_nx", ctypes.c_float), ("inv_ny", ctypes.c_float),
         ("disp", ctypes.c_void_p), ("tgt", ctypes.c_void_p), ("src", ctypes.c_void_p * MAX_SRC),
         ("K", ctypes.c_void_p), ("invK", ctypes.c_void_p), ("T", ctypes.c_void_p * MAX_SRC),
-        ("noise", ctypes.c_void_p), ("seed", ctypes.c_ulonglong),
+        ("noise", ctypes.c_void_p), ("seed", ctypes.c_ulonglong), ("idmin", ctypes.c_void_p),
         ("gphoto", ctypes.c_void_p), ("gedge", ctypes.c_void_p), ("ident_sel", ctypes.c_void_p),
         ("partials", ctypes.c_void_p), ("counter", ctypes.c_void_p), ("want_grad", ctypes.c_int),
     ]
@@ -65,6 +65,7 @@ def run_emu(disp, target, sources, K, inv_K, Ts, noise, automask=True, avg=False
     gphoto = np.full((B, H, W), np.nan, np.float32)
     gedge = np.full((B, H, W), np.nan, np.float32)
     ident = np.full((B, H, W), np.nan, np.float32)
+    idmin = np.full((B, H, W), np.nan, np.float32)
 
     n_scales = len(scale_weights)
     photo_w = n_scales * inv_num_scales
@@ -91,6 +92,7 @@ def run_emu(disp, target, sources, K, inv_K, Ts, noise, automask=True, avg=False
     kp.seed = seed
     kp.gphoto, kp.gedge, kp.ident_sel, kp.partials = _ptr(gphoto), _ptr(gedge), _ptr(ident), _ptr(partials)
     kp.counter = None
+    kp.idmin = _ptr(idmin)
     kp.want_grad = 1
     rc = lib.vsl_emu_tiles(ctypes.byref(kp), int(avg))
     assert rc == 0
