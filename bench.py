@@ -50,6 +50,9 @@ class LossStep:
         S = len(srcs)
         self.descs, self.ws, self.losses, self.gdisp, self.gT, self.gT_ptrs = [], [], [], [], [], []
         self.ident = torch.empty(B, H, W, device=dev)
+        # identity-reprojection minimum: depends on the images only, computed once per step
+        # and shared by every disparity head of the batch
+        self.idmin = torch.empty(B, H, W, device=dev) if automask else None
         for h in range(heads):
             d = abi.LossDesc()
             d.B, d.H, d.W, d.S = B, H, W, S
@@ -66,7 +69,8 @@ class LossStep:
                 d.T[s] = (t["stereo_T"] if f == "s" else t[("cam_T_cam", f)]).data_ptr()
             d.K, d.inv_K = t["K"].data_ptr(), t["inv_K"].data_ptr()
             d.noise = None          # in-kernel counter-based tie-break noise
-            d.seed = 1234 + h
+            d.seed = 1234
+            d.identity_min = self.idmin.data_ptr() if automask else None
             n = abi.lib.vsl_loss_workspace_bytes(ctypes.byref(d))
             self.descs.append(d)
             self.ws.append(torch.empty(n, dtype=torch.uint8, device=dev))
@@ -81,6 +85,8 @@ class LossStep:
 
     def __call__(self, stream):
         abi = self.abi
+        if self.idmin is not None:
+            abi.check(abi.lib.vsl_identity_min(ctypes.byref(self.descs[0]), self.idmin.data_ptr(), stream))
         for h, d in enumerate(self.descs):
             ws = self.ws[h]
             abi.check(abi.lib.vsl_loss_forward(ctypes.byref(d), ws.data_ptr(), ws.numel(), self.losses[h].data_ptr(),

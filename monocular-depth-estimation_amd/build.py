@@ -26,7 +26,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -ffp-contract=on: fuse a*b+c only inside one expression.  The default (fast) also fuses
     # across statements, which measurably moves the pose/disparity gradients away from the
     # reference's float32 results (1.5e-5 instead of 1e-6 relative on the golden fixtures).
-    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=on", "-shared", "-fPIC",
+    # -fno-slp-vectorize: packed f32 math has no rate advantage on gfx950 and its operand pairing costs
+    # register moves (measured 3 % slower with it).
+    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=on", "-fno-slp-vectorize", "-shared", "-fPIC",
            "-I", os.path.join(HERE, "..", "include"), "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -35,6 +35,9 @@
 #define VSL_FSUB(a, b) __fsub_rn((a), (b))
 #define VSL_FDIV(a, b) __fdiv_rn((a), (b))
 #define VSL_EXP(x) __expf(x)
+// keeps the instruction scheduler from interleaving the unrolled per-channel / per-source bodies
+// (interleaving them multiplies the number of live registers)
+#define VSL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 // host build: compile with -ffp-contract=off so that a*b+c is never fused
 #define VSL_DEV inline
@@ -43,6 +46,7 @@
 #define VSL_FSUB(a, b) ((a) - (b))
 #define VSL_FDIV(a, b) ((a) / (b))
 #define VSL_EXP(x) expf(x)
+#define VSL_SCHED_FENCE()
 #endif
 
 #ifndef VSL_NC
@@ -85,6 +89,9 @@ struct KParams {
   float* partials;   // [blocks][kPartStride]
   unsigned int* counter;  // arrival counter of the finalize kernel, cleared here
   int want_grad;
+#ifdef VSL_STAMPS
+  unsigned long long* stamps;  // diagnostic build: [blocks][waves][16] shader-clock samples
+#endif
 };
 
 // ----------------------------------------------------------------------------
@@ -100,8 +107,7 @@ VSL_DEV int reflect_clamp(int i, int n) {
 
 VSL_DEV float fast_rcp(float x) {
 #if defined(__HIPCC__) && !defined(VSL_EXACT_RCP)
-  float r = __builtin_amdgcn_rcpf(x);
-  return fmaf(fmaf(-x, r, 1.0f), r, r);  // one Newton step: ~0.5 ulp
+  return __builtin_amdgcn_rcpf(x);  // 1 ulp; the results that must be bit-exact use VSL_FDIV
 #else
   return 1.0f / x;
 #endif
@@ -155,9 +161,13 @@ VSL_DEV Taps axis_taps(float g, int n) {
   return tp;
 }
 
-struct Chain {  // what phase 3 needs from phase 1 for one (pixel, source)
-  float dpx[3], dpy[3];  // d warped_c / d ix, d iy (already zero outside the clip range)
-  float u, v, inv_den;
+// What phase 3 needs from phase 1 for one (pixel, source): where the four bilinear taps are and
+// their fractions.  Three registers instead of the six tap derivatives; phase 3 fetches the taps
+// again (they are cache hits) and rebuilds the derivatives.
+struct Chain {
+  float tx, ty;  // bilinear fractions
+  int packed;    // bits 0..27 offset of tap (y0,x0) in the image plane, 28: x1 = x0+1, 29: y1 = y0+1,
+                 // 30: d/dx passes (0 < ix < W-1), 31: d/dy passes
 };
 
 template <int S>
@@ -205,8 +215,16 @@ VSL_DEV void y_stats(const float yw[3][4], float sy[2], float syy[2]) {
     c1[j] = (e0 + e1) + e2;
     c2[j] = fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
   }
-  two_windows(c1, sy);
-  two_windows(c2, syy);
+  float s1[2], s2[2];
+  two_windows(c1, s1);
+  two_windows(c2, s2);
+  // handed on as: centre-relative mean  myp = s1/9  and  variance + C2  (both shared by every source)
+  constexpr float i9 = 1.0f / 9.0f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    sy[k] = s1[k] * i9;
+    syy[k] = fmaf(s2[k], i9, -sy[k] * sy[k]) + kC2;
+  }
 }
 
 struct SsimOut {
@@ -215,17 +233,17 @@ struct SsimOut {
 };
 
 // layers.py:252-262 from centre-relative sums (cx, cy = the common centre values)
-VSL_DEV SsimOut ssim_formula(float cx, float cy, float sx, float sxx, float sxy, float sy, float syy, bool want_coef) {
+// (myp, vyc) = the target side from y_stats: centre-relative mean and variance + C2
+VSL_DEV SsimOut ssim_formula(float cx, float cy, float sx, float sxx, float sxy, float myp, float vyc, bool want_coef) {
   constexpr float i9 = 1.0f / 9.0f;
-  const float mxp = sx * i9, myp = sy * i9;
+  const float mxp = sx * i9;
   const float mux = cx + mxp, muy = cy + myp;
   const float vx = fmaf(sxx, i9, -mxp * mxp);
-  const float vy = fmaf(syy, i9, -myp * myp);
   const float cxy = fmaf(sxy, i9, -mxp * myp);
   const float n1 = fmaf(2.0f * mux, muy, kC1);
   const float n2 = fmaf(2.0f, cxy, kC2);
   const float d1 = fmaf(mux, mux, fmaf(muy, muy, kC1));
-  const float d2 = vx + vy + kC2;
+  const float d2 = vx + vyc;
   const float inv = fast_rcp(d1 * d2);
   const float val = fmaf(-0.5f * n1, n2 * inv, 0.5f);
   SsimOut o;
@@ -273,9 +291,9 @@ VSL_DEV void ssim_pair(const float xw[3][4], const float yw[3][4], const float s
 template <int TW, int TH, int NT, int S, bool AVG>
 struct Ident {
   static constexpr int RW = TW + 2, RH = TH + 2, PN = RW * RH;
-  static constexpr int NPAIR = (TW / 2) * TH;
+  static constexpr int ROWP = 16;
   static constexpr int LDS_FLOATS = (3 + 3 * S) * PN;
-  static_assert(NPAIR <= NT && PN % 2 == 0 && TW % 2 == 0, "tile / thread mismatch");
+  static_assert(TW / 2 <= ROWP && ROWP * TH <= NT && PN % 2 == 0 && TW % 2 == 0, "tile / thread mismatch");
 
   struct Block {
     int b, x0, y0;
@@ -298,8 +316,8 @@ struct Ident {
   }
 
   static VSL_DEV void compute(const KParams& kp, const Block& bk, int tid, const float* lds) {
-    if (tid >= NPAIR) return;
-    const int iy = tid / (TW / 2), ip = tid % (TW / 2);
+    const int iy = tid / ROWP, ip = tid % ROWP;
+    if (iy >= TH || ip >= TW / 2) return;
     const int gy = bk.y0 + iy, gx0 = bk.x0 + 2 * ip;
     if (gy >= kp.H || gx0 >= kp.W) return;
     const int base = iy * RW + 2 * ip;
@@ -362,12 +380,13 @@ struct Fused {
   static_assert(TW % 2 == 0, "tile width must be even");
   static constexpr int R2W = TW + 4, R2H = TH + 4, P2 = R2W * R2H;
   static constexpr int R1W = TW + 2, R1H = TH + 2, P1 = R1W * R1H;
-  static constexpr int NPAIR1 = (R1W / 2) * R1H;
-  static constexpr int NPAIR0 = (TW / 2) * TH;
-  static constexpr int NHALO = P2 - TW * TH;
+  // Threads map to pixel pairs as (row = tid / ROWP, pair = tid % ROWP) in every phase.  ROWP = 16
+  // makes each 16-lane LDS access group lie inside one tile row, which keeps the 8-byte window
+  // reads and coefficient writes free of bank conflicts (a row is at most 32 dwords).
+  static constexpr int ROWP = 16;
   static constexpr int NSET = AVG ? S : 1;
   static constexpr int NPART = num_partials(S);
-  static_assert(NPAIR1 <= NT && NPAIR0 <= NT, "not enough threads for the tile");
+  static_assert(R2W / 2 <= ROWP && ROWP * R2H <= NT, "one R2 pair per thread, at most ROWP pairs per row");
   static_assert(P2 % 2 == 0 && P1 % 2 == 0, "planes must keep 8-byte alignment");
 
   // LDS layout in floats
@@ -401,115 +420,85 @@ struct Fused {
     }
   }
 
-  // ---- phase 1: one R2 position --------------------------------------------
-  static VSL_DEV void warp_position(const KParams& kp, const Block& bk, int ry, int rx, float* lds, Chain* chain) {
-    const int H = kp.H, W = kp.W;
-    const int py = reflect_clamp(bk.y0 - 2 + ry, H);
-    const int px = reflect_clamp(bk.x0 - 2 + rx, W);
-    const int p2 = ry * R2W + rx;
-    const size_t HW = (size_t)H * W;
-    const size_t pix = (size_t)py * W + px;
-    const size_t img0 = (size_t)bk.b * 3 * HW;
-
-    const float d = kp.disp[(size_t)bk.b * HW + pix];
-    lds[OFF_DSP + p2] = d;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) lds[OFF_TGT + c * P2 + p2] = kp.tgt[img0 + c * HW + pix];
-
-    // disp_to_depth and the back-projected ray, layers.py:21-25,163-169
-    const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
-    const float D = VSL_FDIV(1.0f, sd);
-    const float fx = (float)px, fy = (float)py;
-    const float* ik = lds + OFF_MAT + 12 * S;
-    float X[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float r = VSL_FMUL(ik[i * 3 + 0], fx);
-      r = fmaf(ik[i * 3 + 1], fy, r);
-      r = fmaf(ik[i * 3 + 2], 1.0f, r);
-      X[i] = VSL_FMUL(D, r);
-    }
-    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float* P = lds + OFF_MAT + 12 * s;
-      float cam[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float a = VSL_FMUL(P[i * 4 + 0], X[0]);
-        a = fmaf(P[i * 4 + 1], X[1], a);
-        a = fmaf(P[i * 4 + 2], X[2], a);
-        a = fmaf(P[i * 4 + 3], 1.0f, a);
-        cam[i] = a;
-      }
-      // layers.py:196-201
-      const float den = VSL_FADD(cam[2], kp.eps);
-      const float u = VSL_FDIV(cam[0], den), v = VSL_FDIV(cam[1], den);
-      const float gx = VSL_FMUL(VSL_FSUB(VSL_FDIV(u, wm1), 0.5f), 2.0f);
-      const float gy = VSL_FMUL(VSL_FSUB(VSL_FDIV(v, hm1), 0.5f), 2.0f);
-      const Taps tx = axis_taps(gx, W), ty = axis_taps(gy, H);
-      const float* sp = kp.src[s] + img0;
-      const size_t o00 = (size_t)ty.i0 * W + tx.i0, o01 = (size_t)ty.i0 * W + tx.i1;
-      const size_t o10 = (size_t)ty.i1 * W + tx.i0, o11 = (size_t)ty.i1 * W + tx.i1;
-      const float w00 = (1.0f - tx.t) * (1.0f - ty.t), w01 = tx.t * (1.0f - ty.t);
-      const float w10 = (1.0f - tx.t) * ty.t, w11 = tx.t * ty.t;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float v00 = sp[c * HW + o00], v01 = sp[c * HW + o01];
-        const float v10 = sp[c * HW + o10], v11 = sp[c * HW + o11];
-        lds[OFF_WRP + (s * 3 + c) * P2 + p2] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
-        if (chain) {
-          chain[s].dpx[c] = tx.live * ((1.0f - ty.t) * (v01 - v00) + ty.t * (v11 - v10));
-          chain[s].dpy[c] = ty.live * ((1.0f - tx.t) * (v10 - v00) + tx.t * (v11 - v01));
-        }
-      }
-      if (chain) {
-        chain[s].u = u;
-        chain[s].v = v;
-        chain[s].inv_den = VSL_FDIV(1.0f, den);
-      }
-    }
-  }
-
-  static VSL_DEV void halo_item(const KParams& kp, const Block& bk, int h, float* lds) {
-    int ry, rx;
-    if (h < 2 * R2W) {  // two top rows
-      ry = h / R2W;
-      rx = h % R2W;
-    } else if (h < 4 * R2W) {  // two bottom rows
-      ry = TH + 2 + (h - 2 * R2W) / R2W;
-      rx = (h - 2 * R2W) % R2W;
-    } else {  // left / right two columns of the middle rows
-      const int m = h - 4 * R2W;
-      ry = 2 + m / 4;
-      const int c = m % 4;
-      rx = (c < 2) ? c : TW + c;
-    }
-    warp_position(kp, bk, ry, rx, lds, nullptr);
-  }
-
+  // ---- phase 1: two horizontally adjacent R2 positions per thread -------------------
+  // Every thread warps exactly one pair of R2 and keeps where its taps were; the threads whose
+  // pair is interior use that again in phase 3.
   static VSL_DEV void phase1(const KParams& kp, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
     st.photo = 0.0f;
-    if (tid < NPAIR0) {
-      const int iy = tid / (TW / 2), ip = tid % (TW / 2);
+    const int ry = tid / ROWP, rx0 = 2 * (tid % ROWP);
+    if (ry >= R2H || rx0 >= R2W) return;
+    const int H = kp.H, W = kp.W;
+    const size_t HW = (size_t)H * W;
+    const size_t img0 = (size_t)bk.b * 3 * HW;
+    const int py = reflect_clamp(bk.y0 - 2 + ry, H);
+    const float* ik = lds + OFF_MAT + 12 * S;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    const float fy = (float)py;
+    // rays share the y part: inv_K[i][1]*y is added after inv_K[i][0]*x in the reference's order
 #pragma unroll
-      for (int k = 0; k < 2; ++k) warp_position(kp, bk, 2 + iy, 2 + 2 * ip + k, lds, st.ch[k]);
-    }
-    // halo ring of R2: the threads without an interior pair take three positions
-    // each, the remainder goes to the first threads
-    constexpr int EXTRA = NT - NPAIR0;
-    constexpr int NH_A = (3 * EXTRA < NHALO) ? 3 * EXTRA : NHALO;
-    if (tid >= NPAIR0) {
-      for (int h = tid - NPAIR0; h < NH_A; h += EXTRA) halo_item(kp, bk, h, lds);
-    } else {
-      for (int h = NH_A + tid; h < NHALO; h += NPAIR0) halo_item(kp, bk, h, lds);
+    for (int k = 0; k < 2; ++k) {
+      const int px = reflect_clamp(bk.x0 - 2 + rx0 + k, W);
+      const int p2 = ry * R2W + rx0 + k;
+      const size_t pix = (size_t)py * W + px;
+      const float d = kp.disp[(size_t)bk.b * HW + pix];
+      lds[OFF_DSP + p2] = d;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) lds[OFF_TGT + c * P2 + p2] = kp.tgt[img0 + c * HW + pix];
+
+      // disp_to_depth and the back-projected ray, layers.py:21-25,163-169
+      const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
+      const float D = VSL_FDIV(1.0f, sd);
+      const float fx = (float)px;
+      float X[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float r = VSL_FMUL(ik[i * 3 + 0], fx);
+        r = fmaf(ik[i * 3 + 1], fy, r);
+        r = fmaf(ik[i * 3 + 2], 1.0f, r);
+        X[i] = VSL_FMUL(D, r);
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float* P = lds + OFF_MAT + 12 * s;
+        float cam[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          float a = VSL_FMUL(P[i * 4 + 0], X[0]);
+          a = fmaf(P[i * 4 + 1], X[1], a);
+          a = fmaf(P[i * 4 + 2], X[2], a);
+          a = fmaf(P[i * 4 + 3], 1.0f, a);
+          cam[i] = a;
+        }
+        // layers.py:196-201
+        const float den = VSL_FADD(cam[2], kp.eps);
+        const float u = VSL_FDIV(cam[0], den), v = VSL_FDIV(cam[1], den);
+        const float gx = VSL_FMUL(VSL_FSUB(VSL_FDIV(u, wm1), 0.5f), 2.0f);
+        const float gy = VSL_FMUL(VSL_FSUB(VSL_FDIV(v, hm1), 0.5f), 2.0f);
+        const Taps tx = axis_taps(gx, W), ty = axis_taps(gy, H);
+        const float* sp = kp.src[s] + img0;
+        const int o00 = ty.i0 * W + tx.i0, o01 = ty.i0 * W + tx.i1;
+        const int o10 = ty.i1 * W + tx.i0, o11 = ty.i1 * W + tx.i1;
+        const float w00 = (1.0f - tx.t) * (1.0f - ty.t), w01 = tx.t * (1.0f - ty.t);
+        const float w10 = (1.0f - tx.t) * ty.t, w11 = tx.t * ty.t;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float v00 = sp[c * HW + o00], v01 = sp[c * HW + o01];
+          const float v10 = sp[c * HW + o10], v11 = sp[c * HW + o11];
+          lds[OFF_WRP + (s * 3 + c) * P2 + p2] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+        }
+        Chain& ch = st.ch[k][s];
+        ch.tx = tx.t;
+        ch.ty = ty.t;
+        ch.packed = o00 | ((tx.i1 != tx.i0) << 28) | ((ty.i1 != ty.i0) << 29) | ((tx.live != 0.0f) << 30) |
+                    ((ty.live != 0.0f) << 31);
+      }
     }
   }
 
   // ---- phase 2: photometric error on R1, running argmin, coefficients -----------
   static VSL_DEV void phase2(const KParams& kp, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
-    if (tid >= NPAIR1) return;
-    const int qy = tid / (R1W / 2), qx0 = 2 * (tid % (R1W / 2));
+    const int qy = tid / ROWP, qx0 = 2 * (tid % ROWP);
+    if (qy >= R1H || qx0 >= R1W) return;
     const int gy = bk.y0 - 1 + qy, gx0 = bk.x0 - 1 + qx0;
     const bool rowv = gy >= 0 && gy < kp.H;
     const bool rowi = qy >= 1 && qy <= TH;
@@ -545,6 +534,7 @@ struct Fused {
         float yw[3][4];
         load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
         y_stats(yw, sy[c], syy[c]);
+        VSL_SCHED_FENCE();
       }
     }
 #pragma unroll
@@ -569,6 +559,7 @@ struct Fused {
           cf[k][c * 3 + 1] = o[k].B;
           cf[k][c * 3 + 2] = o[k].G;
         }
+        VSL_SCHED_FENCE();
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -609,9 +600,9 @@ struct Fused {
 #pragma unroll
     for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
     st.part[0] = st.photo;
-    if (tid >= NPAIR0) return;
     const int H = kp.H, W = kp.W;
-    const int iy = tid / (TW / 2), ip = tid % (TW / 2);
+    const int iy = tid / ROWP - 2, ip = tid % ROWP - 1;  // (R2 row, R2 pair) of phase 1 -> interior coordinates
+    if (iy < 0 || iy >= TH || ip < 0 || ip >= TW / 2) return;
     const int jy = bk.y0 + iy;
     if (jy >= H) return;
     const int jx0 = bk.x0 + 2 * ip;
@@ -640,8 +631,6 @@ struct Fused {
           fxm[k][2] += (float)(jx0 + k == W - 2);
         }
       }
-      float selw[3][4];
-      load_win(sel, qb, R1W, selw);
       const float* ikm = lds + OFF_MAT + 12 * S;
       const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
 
@@ -656,16 +645,35 @@ struct Fused {
         for (int i = 0; i < 3; ++i) r[k][i] = fmaf(ikm[i * 3 + 2], 1.0f, fmaf(ikm[i * 3 + 1], fyv, ikm[i * 3 + 0] * fx));
       }
       float gD[2] = {0.0f, 0.0f};
+      float gcs[S][2][3];  // d L / d cam of (source, pixel); the 3x4 projection gradient is built from it at the end
 
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         // 0/1 mask of the window positions whose winner is source s
         float msk[3][4];
+        load_win(sel, qb, R1W, msk);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) msk[i][j] = AVG ? (float)(selw[i][j] > 0.0f) : (float)(selw[i][j] == (float)s);
-        float gix[2] = {0.0f, 0.0f}, giy[2] = {0.0f, 0.0f};
+          for (int j = 0; j < 4; ++j) msk[i][j] = AVG ? (float)(msk[i][j] > 0.0f) : (float)(msk[i][j] == (float)s);
+        // fetch the bilinear taps of both pixels again (cache hits); they are consumed after the
+        // coefficient gather, which hides their latency
+        float tv[2][3][4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int pk = st.ch[k][s].packed;
+          const int o00 = pk & 0x0FFFFFFF;
+          const int dxo = (pk >> 28) & 1, dyo = ((pk >> 29) & 1) * W;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float* sp = kp.src[s] + ((size_t)bk.b * 3 + c) * HW + o00;
+            tv[k][c][0] = sp[0];
+            tv[k][c][1] = sp[dxo];
+            tv[k][c][2] = sp[dyo];
+            tv[k][c][3] = sp[dyo + dxo];
+          }
+        }
+        float g[2][3];  // d L / d warped_c of both pixels
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           float acc[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
@@ -700,38 +708,65 @@ struct Fused {
           for (int k = 0; k < 2; ++k) {
             const float x = lds[OFF_WRP + (s * 3 + c) * P2 + p2 + k];
             const float y = lds[OFF_TGT + c * P2 + p2 + k];
-            const float selj = selw[1][1 + k];
-            const float picked = AVG ? (float)(selj > 0.0f) : (float)(selj == (float)s);
-            float g = kp.cst_ssim * (acc[k][0] + acc[k][1] * x + acc[k][2] * y);
-            g -= kp.cst_l1 * picked * sgn(y - x);
-            gix[k] = fmaf(g, st.ch[k][s].dpx[c], gix[k]);
-            giy[k] = fmaf(g, st.ch[k][s].dpy[c], giy[k]);
+            g[k][c] = kp.cst_ssim * (acc[k][0] + acc[k][1] * x + acc[k][2] * y) - kp.cst_l1 * msk[1][1 + k] * sgn(y - x);
           }
+          VSL_SCHED_FENCE();
+        }
+        // tap derivatives d warped_c / d ix, d iy (zero outside the clip range) and the chain to (ix, iy)
+        float gix[2] = {0.0f, 0.0f}, giy[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const Chain ch = st.ch[k][s];
+          const float lx = (float)((ch.packed >> 30) & 1), ly = (float)((ch.packed >> 31) & 1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float v00 = tv[k][c][0], v01 = tv[k][c][1], v10 = tv[k][c][2], v11 = tv[k][c][3];
+            const float dpx = (1.0f - ch.ty) * (v01 - v00) + ch.ty * (v11 - v10);
+            const float dpy = (1.0f - ch.tx) * (v10 - v00) + ch.tx * (v11 - v01);
+            gix[k] = fmaf(g[k][c], dpx, gix[k]);
+            giy[k] = fmaf(g[k][c], dpy, giy[k]);
+          }
+          gix[k] *= lx;
+          giy[k] *= ly;
         }
         const float* P = lds + OFF_MAT + 12 * s;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          if (!ok[k]) continue;
+          if (!ok[k]) {
+            gcs[s][k][0] = gcs[s][k][1] = gcs[s][k][2] = 0.0f;
+            continue;
+          }
           // d ix / d gx = W/2, d gx / d u = 2/(W-1)
           const float gu = gix[k] * ((float)W / wm1), gv = giy[k] * ((float)H / hm1);
-          const float id = st.ch[k][s].inv_den;
-          const float gc[3] = {gu * id, gv * id, -(gu * st.ch[k][s].u + gv * st.ch[k][s].v) * id};
+          // projection of this pixel again (layers.py:193-196); gradient only, so a plain reciprocal
+          float cam[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            cam[i] = fmaf(P[i * 4 + 0], D[k] * r[k][0], fmaf(P[i * 4 + 1], D[k] * r[k][1], fmaf(P[i * 4 + 2], D[k] * r[k][2], P[i * 4 + 3])));
+          const float id = fast_rcp(cam[2] + kp.eps);
+          const float gc[3] = {gu * id, gv * id, -(gu * cam[0] + gv * cam[1]) * id * id};
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             const float gX = P[0 * 4 + i] * gc[0] + P[1 * 4 + i] * gc[1] + P[2 * 4 + i] * gc[2];
             gD[k] = fmaf(gX, r[k][i], gD[k]);
           }
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-              st.part[4 + 12 * s + i * 4 + j] = fmaf(gc[i] * D[k], r[k][j], st.part[4 + 12 * s + i * 4 + j]);
-            st.part[4 + 12 * s + i * 4 + 3] += gc[i];
-          }
+          for (int i = 0; i < 3; ++i) gcs[s][k][i] = gc[i];
         }
+        VSL_SCHED_FENCE();
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) g_disp[k] = gD[k] * (-kp.c_disp * D[k] * D[k]);
+      // d L / d P[i][j] = sum over pixels of gc[i] * (D r, 1)[j]
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            st.part[4 + 12 * s + i * 4 + j] = gcs[s][0][i] * (D[0] * r[0][j]) + gcs[s][1][i] * (D[1] * r[1][j]);
+          st.part[4 + 12 * s + i * 4 + 3] = gcs[s][0][i] + gcs[s][1][i];
+        }
     }
 
     // edge-aware smoothness, layers.py:211-226 with the 1/(mean+1e-7) factor applied later

@@ -1,7 +1,7 @@
 // libvsloss.so -- kernels and C-ABI entry points of the fused view-synthesis loss.
 //
 //   vsl_ident_kernel     identity-reprojection minimum per pixel (once per batch)
-//   vsl_fused_kernel     one workgroup per 32x16 tile; the tile program of vsl_fused.hpp
+//   vsl_fused_kernel     one workgroup per 28x16 tile; the tile program of vsl_fused.hpp
 //   vsl_finalize_kernel  one workgroup per image: deterministic float64 reduction of the
 //                        tile records, per-image smoothness factors, pose gradients; the
 //                        last workgroup to finish writes the loss scalars
@@ -9,6 +9,7 @@
 //                        smoothness parts, scaled by the upstream gradient
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/vsloss.h"
@@ -18,9 +19,13 @@ namespace {
 
 using namespace vsl;
 
-constexpr int kTW = 32, kTH = 16, kNT = 320;
+constexpr int kTW = 28, kTH = 12, kNT = 256;
 
 thread_local std::string g_err;
+#ifdef VSL_STAMPS
+unsigned long long* g_stamps = nullptr;
+size_t g_stamp_bytes = 0;
+#endif
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -30,6 +35,23 @@ int fail(int code, const std::string& msg) {
 // --------------------------------------------------------------------------
 // fused tile kernel
 // --------------------------------------------------------------------------
+// Diagnostic build only (-DVSL_STAMPS): lane 0 of every wave records the shader clock at the
+// phase boundaries into a buffer of its own (kp.gedge is redirected by the host tool); the
+// shipped library contains no stamp.
+#ifdef VSL_STAMPS
+#define VSL_STAMP(i)                                                                            \
+  do {                                                                                          \
+    unsigned long long t_;                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    if ((threadIdx.x & 63) == 0)                                                                \
+      kp.stamps[((size_t)block_linear * (kNT / 64) + (threadIdx.x >> 6)) * 16 + (i)] = t_;      \
+  } while (0)
+#else
+#define VSL_STAMP(i)
+#endif
+
 template <int S, bool AVG>
 __global__ __launch_bounds__(kNT, (S <= 2 ? 4 : 3)) void vsl_fused_kernel(const KParams kp) {
   using F = Fused<kTW, kTH, kNT, S, AVG>;
@@ -42,19 +64,43 @@ __global__ __launch_bounds__(kNT, (S <= 2 ? 4 : 3)) void vsl_fused_kernel(const 
   const int block_linear = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 
   ThreadState<S> st;
+#ifdef VSL_STAMPS
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+    unsigned int hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = kp.stamps + ((size_t)block_linear * (kNT / 64) + (threadIdx.x >> 6)) * 16;
+    o[9] = rt;
+    o[11] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
+  VSL_STAMP(0);
   F::phase0(kp, bk, tid, lds);
   __syncthreads();
+  VSL_STAMP(1);
   F::phase1(kp, bk, tid, lds, st);
+  VSL_STAMP(2);
   __syncthreads();
+  VSL_STAMP(3);
   F::phase2(kp, bk, tid, lds, st);
+  VSL_STAMP(4);
   __syncthreads();
+  VSL_STAMP(5);
   F::phase3(kp, bk, tid, lds, st);
+  VSL_STAMP(6);
   __syncthreads();
+  VSL_STAMP(7);
   F::phase4_store(tid, lds, st);
   __syncthreads();
   F::phase4_sum_a(tid, lds);
   __syncthreads();
   F::phase4_sum_b(kp, block_linear, tid, lds);
+  VSL_STAMP(8);
+#ifdef VSL_STAMPS
+  if ((threadIdx.x & 63) == 0)
+    kp.stamps[((size_t)block_linear * (kNT / 64) + (threadIdx.x >> 6)) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // --------------------------------------------------------------------------
@@ -92,21 +138,36 @@ struct FinalizeParams {
   float* losses;      // [VSL_LOSS_SLOTS]
 };
 
-__global__ __launch_bounds__(256) void vsl_finalize_kernel(const FinalizeParams fp) {
-  __shared__ double red[4][64];
+__global__ __launch_bounds__(1024) void vsl_finalize_kernel(const FinalizeParams fp) {
+  __shared__ double red[16][64];
   __shared__ double tot[64];
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
-  const int v = tid & 63, r = tid >> 6;
+  const int v = tid & 63, r = tid >> 6;  // value index, row group (16 tile records in flight per step)
   const int npart = num_partials(fp.S);
-  double acc = 0.0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (v < npart) {
     const float* base = fp.partials + (size_t)b * fp.tiles_per_image * kPartStride + v;
-    for (int t = r; t < fp.tiles_per_image; t += 4) acc += (double)base[(size_t)t * kPartStride];
+    const int n = fp.tiles_per_image;
+    int t = r;
+    for (; t + 48 < n; t += 64) {  // four independent loads per step, fixed association order
+      const float x0 = base[(size_t)t * kPartStride], x1 = base[(size_t)(t + 16) * kPartStride];
+      const float x2 = base[(size_t)(t + 32) * kPartStride], x3 = base[(size_t)(t + 48) * kPartStride];
+      a0 += (double)x0;
+      a1 += (double)x1;
+      a2 += (double)x2;
+      a3 += (double)x3;
+    }
+    for (; t < n; t += 16) a0 += (double)base[(size_t)t * kPartStride];
   }
-  red[r][v] = acc;
+  red[r][v] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (tid < 64) tot[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  if (tid < 64) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][tid];
+    tot[tid] = s;
+  }
   __syncthreads();
 
   const double HW = (double)fp.H * fp.W;
@@ -239,6 +300,7 @@ int check_desc(const vsl_loss_desc* d) {
   if (d->B > 65535) return fail(VSL_ERR_INVALID_ARGUMENT, "B exceeds 65535");
   if ((long long)d->B * d->H * d->W * 3 >= (1ll << 31))
     return fail(VSL_ERR_INVALID_ARGUMENT, "B*3*H*W must stay below 2^31");
+  if ((long long)d->H * d->W >= (1ll << 28)) return fail(VSL_ERR_INVALID_ARGUMENT, "H*W must stay below 2^28");
   if (d->S < 1 || d->S > VSL_MAX_SOURCES) return fail(VSL_ERR_INVALID_ARGUMENT, "S must be 1..VSL_MAX_SOURCES");
   if (d->n_scales < 1 || d->n_scales > VSL_MAX_SCALES)
     return fail(VSL_ERR_INVALID_ARGUMENT, "n_scales must be 1..VSL_MAX_SCALES");
@@ -258,11 +320,15 @@ int launch_fused(const KParams& kp, dim3 grid, hipStream_t stream) {
   static thread_local bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vsl_fused_kernel<S, AVG>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(VSL_ERR_LAUNCH_FAILED, "hipFuncSetAttribute(max dynamic LDS) failed");
     configured = true;
   }
-  hipLaunchKernelGGL((vsl_fused_kernel<S, AVG>), grid, dim3(kNT), lds_bytes, stream, kp);
+  size_t launch_lds = lds_bytes;
+#ifdef VSL_STAMPS
+  if (const char* e = getenv("VSL_DEBUG_EXTRA_LDS")) launch_lds += (size_t)atoi(e);  // diagnostic: fewer resident blocks
+#endif
+  hipLaunchKernelGGL((vsl_fused_kernel<S, AVG>), grid, dim3(kNT), launch_lds, stream, kp);
   return VSL_OK;
 }
 
@@ -365,6 +431,17 @@ int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_b
   kp.counter = (unsigned int*)(ws + L.off_counter);
 
   const dim3 grid(L.tiles_x, L.tiles_y, d->B);
+#ifdef VSL_STAMPS
+  {
+    const size_t need = (size_t)L.blocks * (kNT / 64) * 16 * sizeof(unsigned long long);
+    if (g_stamp_bytes < need) {
+      if (g_stamps) (void)hipFree(g_stamps);
+      if (hipMalloc((void**)&g_stamps, need) != hipSuccess) return fail(VSL_ERR_LAUNCH_FAILED, "stamp buffer");
+      g_stamp_bytes = need;
+    }
+    kp.stamps = g_stamps;
+  }
+#endif
   if (automask) {
     if (d->identity_min) {
       kp.idmin = const_cast<float*>(d->identity_min);
@@ -401,10 +478,39 @@ int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_b
   fp.c12 = (float*)(ws + L.off_c12);
   fp.counter = (unsigned int*)(ws + L.off_counter);
   fp.losses = losses;
-  hipLaunchKernelGGL(vsl_finalize_kernel, dim3(d->B), dim3(256), 0, stream, fp);
+  hipLaunchKernelGGL(vsl_finalize_kernel, dim3(d->B), dim3(1024), 0, stream, fp);
   if (hipError_t e = hipGetLastError(); e != hipSuccess)
     return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return VSL_OK;
+}
+
+#ifdef VSL_STAMPS
+// diagnostic build: copy the phase time stamps of the last fused launch to the host
+long long vsl_debug_read_stamps(void* host_out, long long max_bytes) {
+  if (!g_stamps) return 0;
+  (void)hipDeviceSynchronize();
+  const size_t n = g_stamp_bytes < (size_t)max_bytes ? g_stamp_bytes : (size_t)max_bytes;
+  if (hipMemcpy(host_out, g_stamps, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (long long)n;
+}
+#endif
+
+// diagnostic: resident workgroups per CU the runtime predicts for the fused kernel
+int vsl_debug_fused_occupancy(int S, int avg) {
+  int n = -1;
+  auto q = [&](auto kern, size_t lds) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kNT, lds); };
+  switch (S * 2 + (avg ? 1 : 0)) {
+    case 2: q(vsl_fused_kernel<1, false>, Fused<kTW, kTH, kNT, 1, false>::LDS_FLOATS * 4); break;
+    case 3: q(vsl_fused_kernel<1, true>, Fused<kTW, kTH, kNT, 1, true>::LDS_FLOATS * 4); break;
+    case 4: q(vsl_fused_kernel<2, false>, Fused<kTW, kTH, kNT, 2, false>::LDS_FLOATS * 4); break;
+    case 5: q(vsl_fused_kernel<2, true>, Fused<kTW, kTH, kNT, 2, true>::LDS_FLOATS * 4); break;
+    case 6: q(vsl_fused_kernel<3, false>, Fused<kTW, kTH, kNT, 3, false>::LDS_FLOATS * 4); break;
+    case 7: q(vsl_fused_kernel<3, true>, Fused<kTW, kTH, kNT, 3, true>::LDS_FLOATS * 4); break;
+    case 8: q(vsl_fused_kernel<4, false>, Fused<kTW, kTH, kNT, 4, false>::LDS_FLOATS * 4); break;
+    case 9: q(vsl_fused_kernel<4, true>, Fused<kTW, kTH, kNT, 4, true>::LDS_FLOATS * 4); break;
+    default: break;
+  }
+  return n;
 }
 
 int vsl_identity_min(const vsl_loss_desc* d, float* identity_min, void* stream_) {

@@ -13,7 +13,7 @@
 using namespace vsl;
 
 namespace {
-constexpr int kTW = 32, kTH = 16, kNT = 320;
+constexpr int kTW = 28, kTH = 12, kNT = 256;
 
 template <int S, bool AVG>
 void run_ident(const KParams& kp) {
