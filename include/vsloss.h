@@ -121,8 +121,58 @@ int vsl_identity_min(const vsl_loss_desc* desc, float* identity_min, void* strea
 int vsl_loss_backward(const vsl_loss_desc* desc, const void* workspace, size_t workspace_bytes,
                       const float* grad_losses, float* grad_disp, float* const* grad_T, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Per-module entry points: one for each layers.py primitive, forward and
+ * backward, for callers that use the modules one at a time.  All tensors are
+ * float32, contiguous, on the device.
+ * ---------------------------------------------------------------------- */
+
+/* disp_to_depth (Python/layers.py:16-25): scaled = 1/max + (1/min - 1/max) * disp, depth = 1/scaled.
+ * scaled / depth (and g_scaled / g_depth) may be NULL when not wanted. */
+int vsl_disp_to_depth_fwd(const float* disp, float* scaled, float* depth, long long n, float min_depth, float max_depth,
+                          void* stream);
+int vsl_disp_to_depth_bwd(const float* disp, const float* g_scaled, const float* g_depth, float* g_disp, long long n,
+                          float min_depth, float max_depth, void* stream);
+
+/* BackprojectDepth.forward (Python/layers.py:161-174): depth [B,1,H,W], inv_K [B,4,4] -> points [B,4,H*W]. */
+int vsl_backproject_fwd(const float* depth, const float* inv_K, float* points, int B, int H, int W, void* stream);
+int vsl_backproject_bwd(const float* g_points, const float* inv_K, float* g_depth, int B, int H, int W, void* stream);
+
+/* Project3D.forward (Python/layers.py:188-202): points [B,4,H*W], K, T [B,4,4] -> grid [B,H,W,2].
+ * Backward: g_points [B,4,H*W], g_T, g_K [B,4,4] (each may be NULL). */
+int vsl_project_fwd(const float* points, const float* K, const float* T, float* grid, int B, int H, int W, float eps,
+                    void* stream);
+size_t vsl_project_bwd_workspace_bytes(int B, int H, int W);
+int vsl_project_bwd(const float* points, const float* K, const float* T, const float* g_grid, float* g_points, float* g_T,
+                    float* g_K, void* workspace, size_t workspace_bytes, int B, int H, int W, float eps, void* stream);
+
+/* F.grid_sample(image, grid, mode="bilinear", padding_mode="border", align_corners=False)
+ * (Python/Trainer.py:467): image [B,C,Hi,Wi], grid [B,Ho,Wo,2] -> out [B,C,Ho,Wo].  Backward: g_grid
+ * and/or g_image (NULL to skip); g_image is accumulated with float atomics (feature warping,
+ * Python/Train_distillation_new.py:1159-1182), so its last bits depend on the arrival order. */
+int vsl_grid_sample_fwd(const float* image, const float* grid, float* out, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                        void* stream);
+int vsl_grid_sample_bwd(const float* image, const float* grid, const float* g_out, float* g_grid, float* g_image, int B,
+                        int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* SSIM.forward (Python/layers.py:245-262) over `planes` = B*C images of H x W: out = clamp((1-SSIM)/2, 0, 1).
+ * Backward gives the gradient with respect to x; SSIM is symmetric, so swap x and y for the other one. */
+int vsl_ssim_fwd(const float* x, const float* y, float* out, int planes, int H, int W, void* stream);
+int vsl_ssim_bwd(const float* x, const float* y, const float* g_out, float* g_x, int planes, int H, int W, void* stream);
+
+/* get_smooth_loss (Python/layers.py:211-226): disp [B,1,H,W], img [B,C,H,W] -> loss (device scalar).
+ * Backward: g_disp = g_loss * d loss / d disp (img carries no gradient in the reference's use). */
+size_t vsl_smooth_workspace_bytes(int B, int H, int W);
+int vsl_smooth_fwd(const float* disp, const float* img, float* loss, void* workspace, size_t workspace_bytes, int B, int C,
+                   int H, int W, void* stream);
+int vsl_smooth_bwd(const float* disp, const float* img, const float* g_loss, float* g_disp, int B, int C, int H, int W,
+                   void* stream);
+
 /* Message of the last error raised on the calling thread ("" if none). */
 const char* vsl_last_error_string(void);
+
+/* Diagnostic: workgroups of the fused kernel the runtime expects to fit on one CU for S sources. */
+int vsl_debug_fused_occupancy(int S, int avg_reprojection);
 
 /* Library version, e.g. 100 for 0.1.0. */
 int vsl_version(void);

@@ -19,7 +19,11 @@ LOSS_TOTAL, LOSS_PHOTO, LOSS_SMOOTH, LOSS_SCALE0 = 0, 1, 2, 3
 LOSS_SLOTS = 3 + MAX_SCALES
 
 EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", "vsl_identity_min",
-           "vsl_last_error_string", "vsl_version")
+           "vsl_disp_to_depth_fwd", "vsl_disp_to_depth_bwd", "vsl_backproject_fwd", "vsl_backproject_bwd",
+           "vsl_project_fwd", "vsl_project_bwd_workspace_bytes", "vsl_project_bwd",
+           "vsl_grid_sample_fwd", "vsl_grid_sample_bwd", "vsl_ssim_fwd", "vsl_ssim_bwd",
+           "vsl_smooth_workspace_bytes", "vsl_smooth_fwd", "vsl_smooth_bwd",
+           "vsl_debug_fused_occupancy", "vsl_last_error_string", "vsl_version")
 
 
 class LossDesc(ctypes.Structure):
@@ -58,6 +62,30 @@ def _load():
                                       ctypes.c_void_p]
     lib.vsl_identity_min.restype = ctypes.c_int
     lib.vsl_identity_min.argtypes = [ctypes.POINTER(LossDesc), ctypes.c_void_p, ctypes.c_void_p]
+    P, I, F, LL, SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
+    sigs = {
+        "vsl_disp_to_depth_fwd": [P, P, P, LL, F, F, P],
+        "vsl_disp_to_depth_bwd": [P, P, P, P, LL, F, F, P],
+        "vsl_backproject_fwd": [P, P, P, I, I, I, P],
+        "vsl_backproject_bwd": [P, P, P, I, I, I, P],
+        "vsl_project_fwd": [P, P, P, P, I, I, I, F, P],
+        "vsl_project_bwd": [P, P, P, P, P, P, P, P, SZ, I, I, I, F, P],
+        "vsl_grid_sample_fwd": [P, P, P, I, I, I, I, I, I, P],
+        "vsl_grid_sample_bwd": [P, P, P, P, P, I, I, I, I, I, I, P],
+        "vsl_ssim_fwd": [P, P, P, I, I, I, P],
+        "vsl_ssim_bwd": [P, P, P, P, I, I, I, P],
+        "vsl_smooth_fwd": [P, P, P, P, SZ, I, I, I, I, P],
+        "vsl_smooth_bwd": [P, P, P, P, I, I, I, I, P],
+        "vsl_debug_fused_occupancy": [I, I],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = args
+    for name in ("vsl_project_bwd_workspace_bytes", "vsl_smooth_workspace_bytes"):
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_size_t
+        fn.argtypes = [I, I, I]
     lib.vsl_last_error_string.restype = ctypes.c_char_p
     lib.vsl_last_error_string.argtypes = []
     lib.vsl_version.restype = ctypes.c_int

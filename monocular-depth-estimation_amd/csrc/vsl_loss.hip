@@ -15,22 +15,26 @@
 #include "../../include/vsloss.h"
 #include "vsl_fused.hpp"
 
-namespace {
-
-using namespace vsl;
-
-constexpr int kTW = 28, kTH = 12, kNT = 256;
-
+namespace vsl_err {
 thread_local std::string g_err;
-#ifdef VSL_STAMPS
-unsigned long long* g_stamps = nullptr;
-size_t g_stamp_bytes = 0;
-#endif
-
+// records the message of the calling thread's last error and returns the code
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+}  // namespace vsl_err
+
+namespace {
+
+using namespace vsl;
+using vsl_err::fail;
+
+constexpr int kTW = 28, kTH = 12, kNT = 256;
+
+#ifdef VSL_STAMPS
+unsigned long long* g_stamps = nullptr;
+size_t g_stamp_bytes = 0;
+#endif
 
 // --------------------------------------------------------------------------
 // fused tile kernel
@@ -381,7 +385,7 @@ KParams base_params(const vsl_loss_desc* d) {
 
 extern "C" {
 
-const char* vsl_last_error_string(void) { return g_err.c_str(); }
+const char* vsl_last_error_string(void) { return vsl_err::g_err.c_str(); }
 
 int vsl_version(void) { return 100; }
 

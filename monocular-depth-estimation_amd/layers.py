@@ -1,0 +1,283 @@
+"""Drop-in counterparts of the reference's ``Python/layers.py`` primitives on the HIP library.
+
+Same names, argument order and return values as the reference:
+
+    disp_to_depth(disp, min_depth, max_depth) -> (scaled_disp, depth)          layers.py:16
+    BackprojectDepth(batch_size, height, width).forward(depth, inv_K)          layers.py:139
+    Project3D(batch_size, height, width, eps=1e-7).forward(points, K, T)       layers.py:177
+    SSIM().forward(x, y)                                                       layers.py:229
+    get_smooth_loss(disp, img)                                                 layers.py:211
+    grid_sample_border(image, grid)   == F.grid_sample(..., padding_mode="border")  Trainer.py:467
+
+All of them run hand-written HIP kernels through the C-ABI, take part in autograd, accept
+float64 inputs (cast to float32 on load: the reference's images are float64) and, unlike the
+reference, take the batch size from the input instead of the constructor.  The pose helpers
+(``transformation_from_parameters`` etc.) are tiny [B,4,4] maths and stay on stock torch ops.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+
+_lib = _abi.lib
+
+
+def _prep(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError("%s must be a GPU tensor (there is no CPU implementation)" % name)
+    return t.float().contiguous()
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+# ------------------------------------------------------------------ disp_to_depth
+class _DispToDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, min_depth, max_depth):
+        scaled, depth = torch.empty_like(disp), torch.empty_like(disp)
+        _abi.check(_lib.vsl_disp_to_depth_fwd(disp.data_ptr(), scaled.data_ptr(), depth.data_ptr(), disp.numel(),
+                                              min_depth, max_depth, _stream(disp)))
+        ctx.save_for_backward(disp)
+        ctx.rng = (min_depth, max_depth)
+        return scaled, depth
+
+    @staticmethod
+    def backward(ctx, g_scaled, g_depth):
+        (disp,) = ctx.saved_tensors
+        g = torch.empty_like(disp)
+        gs = g_scaled.contiguous() if g_scaled is not None else None
+        gd = g_depth.contiguous() if g_depth is not None else None
+        _abi.check(_lib.vsl_disp_to_depth_bwd(disp.data_ptr(), _ptr(gs), _ptr(gd), g.data_ptr(), disp.numel(),
+                                              ctx.rng[0], ctx.rng[1], _stream(disp)))
+        return g, None, None
+
+
+def disp_to_depth(disp, min_depth, max_depth):
+    """Sigmoid disparity -> (scaled disparity, depth), layers.py:16-25."""
+    return _DispToDepth.apply(_prep(disp, "disp"), float(min_depth), float(max_depth))
+
+
+# ------------------------------------------------------------------ BackprojectDepth
+class _Backproject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, inv_K):
+        B, _, H, W = depth.shape
+        pts = torch.empty(B, 4, H * W, dtype=torch.float32, device=depth.device)
+        _abi.check(_lib.vsl_backproject_fwd(depth.data_ptr(), inv_K.data_ptr(), pts.data_ptr(), B, H, W, _stream(depth)))
+        ctx.save_for_backward(inv_K)
+        ctx.shape = (B, H, W)
+        return pts
+
+    @staticmethod
+    def backward(ctx, g_pts):
+        (inv_K,) = ctx.saved_tensors
+        B, H, W = ctx.shape
+        g_pts = g_pts.contiguous()
+        g = torch.empty(B, 1, H, W, dtype=torch.float32, device=g_pts.device)
+        _abi.check(_lib.vsl_backproject_bwd(g_pts.data_ptr(), inv_K.data_ptr(), g.data_ptr(), B, H, W, _stream(g_pts)))
+        return g, None
+
+
+class BackprojectDepth(nn.Module):
+    """Depth image -> homogeneous camera points [B,4,H*W], layers.py:139-174."""
+
+    def __init__(self, batch_size, height, width):
+        super().__init__()
+        self.batch_size, self.height, self.width = batch_size, height, width
+
+    def forward(self, depth, inv_K):
+        depth = _prep(depth, "depth")
+        if depth.dim() != 4 or depth.shape[1] != 1:
+            raise ValueError("depth must be [B,1,H,W]")
+        return _Backproject.apply(depth, _prep(inv_K, "inv_K"))
+
+
+# ------------------------------------------------------------------ Project3D
+class _Project(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, K, T, H, W, eps):
+        B = points.shape[0]
+        grid = torch.empty(B, H, W, 2, dtype=torch.float32, device=points.device)
+        _abi.check(_lib.vsl_project_fwd(points.data_ptr(), K.data_ptr(), T.data_ptr(), grid.data_ptr(), B, H, W, eps,
+                                        _stream(points)))
+        ctx.save_for_backward(points, K, T)
+        ctx.cfg = (B, H, W, eps)
+        return grid
+
+    @staticmethod
+    def backward(ctx, g_grid):
+        points, K, T = ctx.saved_tensors
+        B, H, W, eps = ctx.cfg
+        g_grid = g_grid.contiguous()
+        need = ctx.needs_input_grad
+        g_pts = torch.empty_like(points) if need[0] else None
+        g_K = torch.empty_like(K) if need[1] else None
+        g_T = torch.empty_like(T) if need[2] else None
+        n = _lib.vsl_project_bwd_workspace_bytes(B, H, W)
+        ws = torch.empty(n, dtype=torch.uint8, device=points.device)
+        _abi.check(_lib.vsl_project_bwd(points.data_ptr(), K.data_ptr(), T.data_ptr(), g_grid.data_ptr(), _ptr(g_pts),
+                                        _ptr(g_T), _ptr(g_K), ws.data_ptr(), n, B, H, W, eps, _stream(points)))
+        return g_pts, g_K, g_T, None, None, None
+
+
+class Project3D(nn.Module):
+    """Camera points -> normalised sampling grid [B,H,W,2], layers.py:177-202."""
+
+    def __init__(self, batch_size, height, width, eps=1e-7):
+        super().__init__()
+        self.batch_size, self.height, self.width, self.eps = batch_size, height, width, eps
+
+    def forward(self, points, K, T):
+        points = _prep(points, "points")
+        if points.dim() != 3 or points.shape[1] != 4 or points.shape[2] != self.height * self.width:
+            raise ValueError("points must be [B,4,H*W] for the module's height and width")
+        return _Project.apply(points, _prep(K, "K"), _prep(T, "T"), self.height, self.width, float(self.eps))
+
+
+# ------------------------------------------------------------------ grid_sample (border)
+class _GridSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, grid):
+        B, C, Hi, Wi = image.shape
+        _, Ho, Wo, _ = grid.shape
+        out = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=image.device)
+        _abi.check(_lib.vsl_grid_sample_fwd(image.data_ptr(), grid.data_ptr(), out.data_ptr(), B, C, Hi, Wi, Ho, Wo,
+                                            _stream(image)))
+        ctx.save_for_backward(image, grid)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        image, grid = ctx.saved_tensors
+        B, C, Hi, Wi = image.shape
+        _, Ho, Wo, _ = grid.shape
+        g_out = g_out.contiguous()
+        g_img = torch.empty_like(image) if ctx.needs_input_grad[0] else None
+        g_grid = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
+        _abi.check(_lib.vsl_grid_sample_bwd(image.data_ptr(), grid.data_ptr(), g_out.data_ptr(), _ptr(g_grid), _ptr(g_img),
+                                            B, C, Hi, Wi, Ho, Wo, _stream(image)))
+        return g_img, g_grid
+
+
+def grid_sample_border(image, grid):
+    """``F.grid_sample(image, grid, padding_mode="border")`` (bilinear, align_corners=False), Trainer.py:467."""
+    image, grid = _prep(image, "image"), _prep(grid, "grid")
+    if image.dim() != 4 or grid.dim() != 4 or grid.shape[3] != 2 or grid.shape[0] != image.shape[0]:
+        raise ValueError("image must be [B,C,H,W] and grid [B,Ho,Wo,2]")
+    return _GridSample.apply(image, grid)
+
+
+# ------------------------------------------------------------------ SSIM
+class _Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        _abi.check(_lib.vsl_ssim_fwd(x.data_ptr(), y.data_ptr(), out.data_ptr(), B * C, H, W, _stream(x)))
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = g.contiguous()
+        gx = gy = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _abi.check(_lib.vsl_ssim_bwd(x.data_ptr(), y.data_ptr(), g.data_ptr(), gx.data_ptr(), B * C, H, W, _stream(x)))
+        if ctx.needs_input_grad[1]:     # the measure is symmetric in its two arguments
+            gy = torch.empty_like(y)
+            _abi.check(_lib.vsl_ssim_bwd(y.data_ptr(), x.data_ptr(), g.data_ptr(), gy.data_ptr(), B * C, H, W, _stream(x)))
+        return gx, gy
+
+
+class SSIM(nn.Module):
+    """Per-pixel ``clamp((1 - SSIM(x, y)) / 2, 0, 1)`` over a reflect-padded 3x3 window, layers.py:229-262."""
+
+    def forward(self, x, y):
+        x, y = _prep(x, "x"), _prep(y, "y")
+        if x.shape != y.shape or x.dim() != 4:
+            raise ValueError("x and y must be [B,C,H,W] of the same shape")
+        return _Ssim.apply(x, y)
+
+
+# ------------------------------------------------------------------ get_smooth_loss
+class _Smooth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, img):
+        B, _, H, W = disp.shape
+        C = img.shape[1]
+        loss = torch.empty((), dtype=torch.float32, device=disp.device)
+        n = _lib.vsl_smooth_workspace_bytes(B, H, W)
+        ws = torch.empty(n, dtype=torch.uint8, device=disp.device)
+        _abi.check(_lib.vsl_smooth_fwd(disp.data_ptr(), img.data_ptr(), loss.data_ptr(), ws.data_ptr(), n, B, C, H, W,
+                                       _stream(disp)))
+        ctx.save_for_backward(disp, img)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        disp, img = ctx.saved_tensors
+        B, _, H, W = disp.shape
+        g = g.contiguous().float()
+        gd = torch.empty_like(disp)
+        _abi.check(_lib.vsl_smooth_bwd(disp.data_ptr(), img.data_ptr(), g.data_ptr(), gd.data_ptr(), B, img.shape[1], H, W,
+                                       _stream(disp)))
+        return gd, None
+
+
+def get_smooth_loss(disp, img):
+    """Edge-aware first-order smoothness of a disparity image, layers.py:211-226 (0-dim tensor)."""
+    disp, img = _prep(disp, "disp"), _prep(img, "img")
+    if disp.dim() != 4 or disp.shape[1] != 1 or img.dim() != 4 or img.shape[0] != disp.shape[0] \
+            or img.shape[2:] != disp.shape[2:]:
+        raise ValueError("disp must be [B,1,H,W] and img [B,C,H,W]")
+    return _Smooth.apply(disp, img)
+
+
+# ------------------------------------------------------------------ pose helpers (stock torch; layers.py:28-103)
+def rot_from_axisangle(vec):
+    """Axis-angle [B,1,3] -> rotation [B,4,4], layers.py:64-103."""
+    angle = torch.norm(vec, 2, 2, True)
+    axis = vec / (angle + 1e-7)
+    ca, sa = torch.cos(angle), torch.sin(angle)
+    C = 1 - ca
+    x, y, z = (axis[..., i].unsqueeze(1) for i in range(3))
+    xy, yz, zx = x * (y * C), y * (z * C), z * (x * C)
+    rows = [[x * (x * C) + ca, xy - z * sa, zx + y * sa],
+            [xy + z * sa, y * (y * C) + ca, yz - x * sa],
+            [zx - y * sa, yz + x * sa, z * (z * C) + ca]]
+    R = torch.zeros(vec.shape[0], 4, 4, dtype=vec.dtype, device=vec.device)
+    for i in range(3):
+        for j in range(3):
+            R[:, i, j] = rows[i][j].reshape(-1)
+    R[:, 3, 3] = 1
+    return R
+
+
+def get_translation_matrix(translation_vector):
+    """Translation [B,1,3] -> [B,4,4], layers.py:48-61."""
+    t = translation_vector.contiguous().view(-1, 3)
+    M = torch.eye(4, dtype=t.dtype, device=t.device).repeat(t.shape[0], 1, 1)
+    M[:, :3, 3] = t
+    return M
+
+
+def transformation_from_parameters(axisangle, translation, invert=False):
+    """(axisangle, translation) -> 4x4 pose, layers.py:28-45."""
+    R = rot_from_axisangle(axisangle)
+    t = translation.clone()
+    if invert:
+        R = R.transpose(1, 2)
+        t = t * -1
+    Tm = get_translation_matrix(t)
+    return torch.matmul(R, Tm) if invert else torch.matmul(Tm, R)

@@ -1,0 +1,141 @@
+"""Counterpart of the loss methods of the reference trainers on the HIP library.
+
+``ViewSynthesisLoss`` exposes the call surface of ``Trainer`` (Python/Trainer.py) that the
+hot path consists of, with the same names, dict keys and return values:
+
+    generate_images_pred(inputs, outputs) -> None            Trainer.py:419-479
+    compute_reprojection_loss(pred, target) -> [B,1,H,W]      Trainer.py:481-495
+    compute_losses(inputs, outputs) -> {"loss/{s}", "loss"}   Trainer.py:518-620
+    compute_losses_single(inputs, outputs)                    Trainer_distilation.py:1113-1199
+    compute_losses_distillation(inputs, outputs, ...)         Trainer_distilation.py:1208-1330 (0.9 scale)
+
+``compute_losses`` runs ONE fused kernel pass from the disparity and the poses (it does not
+need ``generate_images_pred`` to have run); ``generate_images_pred`` materialises
+("depth",0), ("sample",f), ("color",f) through the per-module kernels for callers that read
+them (validation dumps, depth metrics).  ``opt`` is the reference's option namespace; the
+fields read are: scales, frame_ids, height, width, min_depth, max_depth, v1_multiscale,
+disable_automasking, avg_reprojection, no_ssim, disparity_smoothness.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _abi
+from .layers import BackprojectDepth, Project3D, SSIM, disp_to_depth, get_smooth_loss, grid_sample_border
+from .ops import fused_view_synthesis_loss
+
+
+class ViewSynthesisLoss:
+    def __init__(self, opt, num_scales: int = 1, photometric_scale: float = 1.0, seed: int = 0):
+        self.opt = opt
+        self.num_scales = num_scales          # the reference fixes this to 1 (Trainer.py:33)
+        self.photometric_scale = photometric_scale
+        self.seed = seed
+        self._step = 0
+        self.backproject_depth = BackprojectDepth(None, opt.height, opt.width)
+        self.project_3d = Project3D(None, opt.height, opt.width)
+        self.ssim = SSIM()
+
+    # ------------------------------------------------------------------ helpers
+    def _sources(self):
+        return list(self.opt.frame_ids[1:])
+
+    def _pose(self, inputs, outputs, f):
+        return inputs["stereo_T"] if f == "s" else outputs[("cam_T_cam", f)]
+
+    def _full_res_disp(self, outputs):
+        disp = outputs[("disp", 0)]
+        if not getattr(self.opt, "v1_multiscale", False) and tuple(disp.shape[2:]) != (self.opt.height, self.opt.width):
+            disp = F.interpolate(disp, [self.opt.height, self.opt.width], mode="bilinear", align_corners=False)
+        return disp
+
+    # ------------------------------------------------------------------ Trainer.py:419-479
+    def generate_images_pred(self, inputs: Dict, outputs: Dict) -> None:
+        disp = self._full_res_disp(outputs)
+        _, depth = disp_to_depth(disp, self.opt.min_depth, self.opt.max_depth)
+        outputs[("depth", 0)] = depth
+        points = self.backproject_depth(depth, inputs["inv_K"])
+        for f in self._sources():
+            grid = self.project_3d(points, inputs["K"], self._pose(inputs, outputs, f))
+            outputs[("sample", f)] = grid
+            outputs[("color", f)] = grid_sample_border(inputs[("image", f)], grid)
+            if not self.opt.disable_automasking:
+                outputs[("color_identity", f)] = inputs[("image", f)]
+
+    # ------------------------------------------------------------------ Trainer.py:481-495
+    def compute_reprojection_loss(self, pred, target):
+        pred = pred.float()
+        target = target.float().to(pred.device)
+        l1 = torch.abs(target - pred).mean(1, True)
+        if self.opt.no_ssim:
+            return l1
+        return 0.85 * self.ssim(pred, target).mean(1, True) + 0.15 * l1
+
+    # ------------------------------------------------------------------ Trainer.py:518-620
+    def compute_losses(self, inputs: Dict, outputs: Dict, noise: Optional[torch.Tensor] = None,
+                       photometric_scale: Optional[float] = None) -> Dict[str, torch.Tensor]:
+        opt = self.opt
+        srcs = self._sources()
+        disp = self._full_res_disp(outputs)
+        automask = not opt.disable_automasking
+        scale_w = [opt.disparity_smoothness / (2 ** s) for s in opt.scales]
+        self._step += 1
+        out, ident = fused_view_synthesis_loss(
+            disp, inputs[("image", 0)], [inputs[("image", f)] for f in srcs], inputs["K"], inputs["inv_K"],
+            [self._pose(inputs, outputs, f) for f in srcs], noise,
+            automask=automask, avg_reprojection=opt.avg_reprojection, no_ssim=opt.no_ssim,
+            scale_weights=scale_w, inv_num_scales=1.0 / self.num_scales,
+            warp_scale=self.photometric_scale if photometric_scale is None else photometric_scale,
+            min_depth=opt.min_depth, max_depth=opt.max_depth, seed=self.seed + self._step)
+        if automask:
+            outputs["identity_selection"] = ident
+        losses = {"loss/{}".format(s): out[_abi.LOSS_SCALE0 + i] for i, s in enumerate(opt.scales)}
+        losses["loss"] = out[_abi.LOSS_TOTAL]
+        return losses
+
+    # Trainer_distilation.py:1113-1199 is the same computation
+    def compute_losses_single(self, inputs, outputs, noise=None):
+        return self.compute_losses(inputs, outputs, noise, photometric_scale=1.0)
+
+    # Trainer_distilation.py:1208-1330 with the encoder-feature Huber terms left to the caller
+    def compute_losses_distillation(self, inputs, outputs, outputs_teacher=None, features=None, teacher_features=None,
+                                    buffered_features=None, noise=None):
+        return self.compute_losses(inputs, outputs, noise, photometric_scale=0.9)
+
+    # ------------------------------------------------------------------ un-fused reference order, for cross-checks
+    def compute_losses_unfused(self, inputs: Dict, outputs: Dict, noise: Optional[torch.Tensor] = None):
+        """Trainer.py:518-620 step by step on the per-module kernels (needs generate_images_pred first)."""
+        opt = self.opt
+        srcs = self._sources()
+        target = inputs[("image", 0)].float()
+        disp = outputs[("disp", 0)]
+        losses, total = {}, 0
+        for scale in opt.scales:
+            warped = torch.cat([self.compute_reprojection_loss(outputs[("color", f)], target) * self.photometric_scale
+                                for f in srcs], 1)
+            if opt.avg_reprojection:
+                warped = warped.mean(1, keepdim=True)
+            if not opt.disable_automasking:
+                ident = torch.cat([self.compute_reprojection_loss(inputs[("image", f)], target) for f in srcs], 1)
+                if opt.avg_reprojection:
+                    ident = ident.mean(1, keepdim=True)
+                z = noise if noise is not None else torch.randn(ident.shape, device=ident.device)
+                combined = torch.cat((ident + z.to(ident.device) * 0.00001, warped), dim=1)
+            else:
+                combined = warped
+            if combined.shape[1] == 1:
+                chosen = combined
+            else:
+                chosen, idx = torch.min(combined, dim=1)
+            if not opt.disable_automasking:
+                outputs["identity_selection"] = (idx > ident.shape[1] - 1).float()
+            loss = chosen.mean()
+            mean_disp = disp.mean(2, True).mean(3, True)
+            loss = loss + opt.disparity_smoothness * get_smooth_loss(disp / (mean_disp + 1e-7), target) / (2 ** scale)
+            total = total + loss
+            losses["loss/{}".format(scale)] = loss
+        losses["loss"] = total / self.num_scales
+        return losses

@@ -1,0 +1,165 @@
+"""GPU parity of the per-module kernels (drop-in layers.py surface) and of the trainer-level
+methods against the reference fixtures and the CPU oracle (float64 where the reference's own
+float32 gradient noise would otherwise dominate).  Tolerances: coordinates bit-exact, values
+and gradients 1e-5 relative (L2)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import build_dicts, fid_key, load_case
+from oracle import vsl_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def test_disp_to_depth_and_backproject_match_fixture_bits():
+    import mde_amd.layers as L
+    cfg, z = load_case("b2_24x80_automask")
+    disp = torch.from_numpy(z["disp"]).to(DEV).requires_grad_(True)
+    scaled, depth = L.disp_to_depth(disp, 0.1, 100.0)
+    assert np.array_equal(depth.detach().cpu().numpy(), z["depth"])
+    pts = L.BackprojectDepth(2, 24, 80)(depth, torch.from_numpy(z["inv_K"]).to(DEV))
+    assert np.array_equal(pts.detach().cpu().numpy(), z["points"])
+    w = torch.from_numpy(np.random.RandomState(0).randn(*z["points"].shape).astype(np.float32)).to(DEV)
+    ((pts * w).sum() + (scaled * 0.3).sum()).backward()
+    d64 = torch.from_numpy(z["disp"]).double().requires_grad_(True)
+    s64, dep64 = O.disp_to_depth(d64, 0.1, 100.0)
+    p64 = O.backproject(dep64.float(), torch.from_numpy(z["inv_K"]))  # float32 rays as in the reference
+    rays = (p64[:, :3] / dep64.float().reshape(2, 1, -1)).double()
+    full = torch.cat([dep64.reshape(2, 1, -1) * rays, torch.ones(2, 1, 24 * 80, dtype=torch.float64)], 1)
+    ((full * w.cpu().double()).sum() + (s64 * 0.3).sum()).backward()
+    assert rel(disp.grad, d64.grad) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["b2_24x80_automask", "b2_24x80_stereo", "b2_24x80_large_motion", "b1_13x37_automask"])
+def test_project3d_grid_is_bit_exact_and_differentiable(name):
+    import mde_amd.layers as L
+    cfg, z = load_case(name)
+    B, H, W = cfg["B"], cfg["H"], cfg["W"]
+    K = torch.from_numpy(z["K"]).to(DEV)
+    for f in [fid_key(f) for f in cfg["frame_ids"]][1:]:
+        pts = torch.from_numpy(z["points"]).to(DEV).requires_grad_(True)
+        T = torch.from_numpy(z["T_%s" % f]).to(DEV).requires_grad_(True)
+        Kg = K.clone().requires_grad_(True)
+        grid = L.Project3D(B, H, W)(pts, Kg, T)
+        assert np.array_equal(grid.detach().cpu().numpy(), z["sample_%s" % f])
+        if name.endswith("large_motion"):
+            continue    # points next to the camera plane: 1/z^2 makes a float32-vs-float64 gradient check meaningless
+        w = torch.from_numpy(np.random.RandomState(1).randn(B, H, W, 2).astype(np.float32)).to(DEV)
+        (grid * w).sum().backward()
+        p64 = torch.from_numpy(z["points"]).double().requires_grad_(True)
+        T64 = torch.from_numpy(z["T_%s" % f]).double().requires_grad_(True)
+        K64 = torch.from_numpy(z["K"]).double().requires_grad_(True)
+        (O.project(p64, K64, T64, H, W) * w.cpu().double()).sum().backward()
+        assert rel(pts.grad, p64.grad) < 1e-5
+        assert rel(T.grad, T64.grad) < 1e-5
+        assert rel(Kg.grad[:, :3], K64.grad[:, :3]) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 24, 80, 24, 80), (1, 5, 7, 9, 12, 10), (2, 16, 6, 20, 6, 20)])
+def test_grid_sample_border_forward_backward(shape):
+    import mde_amd.layers as L
+    B, C, Hi, Wi, Ho, Wo = shape
+    rs = np.random.RandomState(2)
+    img = torch.from_numpy(rs.rand(B, C, Hi, Wi).astype(np.float32))
+    grid = torch.from_numpy((rs.rand(B, Ho, Wo, 2) * 2.6 - 1.3).astype(np.float32))   # partly out of range
+    w = torch.from_numpy(rs.randn(B, C, Ho, Wo).astype(np.float32))
+    ig, gg = img.to(DEV).requires_grad_(True), grid.to(DEV).requires_grad_(True)
+    out = L.grid_sample_border(ig, gg)
+    (out * w.to(DEV)).sum().backward()
+    i64, g64 = img.double().requires_grad_(True), grid.double().requires_grad_(True)
+    ref = F.grid_sample(i64, g64, mode="bilinear", padding_mode="border", align_corners=False)
+    (ref * w.double()).sum().backward()
+    assert rel(out, ref) < 1e-6
+    assert rel(gg.grad, g64.grad) < 1e-5
+    assert rel(ig.grad, i64.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 24, 80), (1, 1, 2, 2), (1, 2, 9, 33), (2, 3, 40, 70)])
+def test_ssim_forward_backward(shape):
+    import mde_amd.layers as L
+    rs = np.random.RandomState(3)
+    import mde_amd.synth as synth
+    x = torch.from_numpy(synth.box_blur(rs.rand(*shape), 3).astype(np.float32))
+    y = torch.from_numpy((synth.box_blur(rs.rand(*shape), 3) * 0.3 + x.numpy() * 0.7).astype(np.float32))
+    w = torch.from_numpy(rs.randn(*shape).astype(np.float32))
+    xg, yg = x.to(DEV).requires_grad_(True), y.to(DEV).requires_grad_(True)
+    out = L.SSIM()(xg, yg)
+    (out * w.to(DEV)).sum().backward()
+    x64, y64 = x.double().requires_grad_(True), y.double().requires_grad_(True)
+    ref = O.ssim(x64, y64)
+    (ref * w.double()).sum().backward()
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 2e-6
+    assert rel(xg.grad, x64.grad) < 1e-5
+    assert rel(yg.grad, y64.grad) < 1e-5
+
+
+def test_ssim_module_matches_fixture():
+    import mde_amd.layers as L
+    cfg, z = load_case("b2_24x80_automask")
+    for f in (-1, 1):
+        out = L.SSIM()(torch.from_numpy(z["color_%s" % f]).to(DEV), torch.from_numpy(z["image_0"]).to(DEV))
+        assert float(np.abs(out.cpu().numpy() - z["ssim_%s" % f]).max()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 80), (1, 2, 2), (3, 17, 31)])
+def test_smooth_loss_forward_backward(shape):
+    import mde_amd.layers as L
+    B, H, W = shape
+    rs = np.random.RandomState(4)
+    disp = torch.from_numpy(rs.rand(B, 1, H, W).astype(np.float32))
+    img = torch.from_numpy(rs.rand(B, 3, H, W).astype(np.float32))
+    dg = disp.to(DEV).requires_grad_(True)
+    loss = L.get_smooth_loss(dg, img.to(DEV))
+    (loss * 1.7).backward()
+    d64 = disp.double().requires_grad_(True)
+    ref = O.smoothness(d64, img.double())
+    (ref * 1.7).backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert rel(dg.grad, d64.grad) < 1e-5
+
+
+def _opt(cfg):
+    return types.SimpleNamespace(
+        scales=cfg["scales"], frame_ids=[fid_key(f) for f in cfg["frame_ids"]], height=cfg["H"], width=cfg["W"],
+        min_depth=0.1, max_depth=100.0, v1_multiscale=False, disable_automasking=not cfg["automask"],
+        avg_reprojection=cfg["avg_reprojection"], no_ssim=cfg["no_ssim"], disparity_smoothness=1e-3)
+
+
+@pytest.mark.parametrize("name", ["b2_24x80_automask", "b2_24x80_stereo", "b2_24x80_scales4", "b2_24x80_noautomask",
+                                  "b2_24x80_distil_scale09", "b1_13x37_noautomask_avg"])
+def test_trainer_surface_matches_reference_fixture(name):
+    from mde_amd.trainer_loss import ViewSynthesisLoss
+    cfg, z = load_case(name)
+    scale = 0.9 if cfg["variant"] == "distil" else 1.0
+    for fused in (True, False):
+        inputs, outputs, disp, poses, noise, fids = build_dicts(cfg, z, image_dtype=torch.float64, device=DEV)
+        vs = ViewSynthesisLoss(_opt(cfg), photometric_scale=scale)
+        vs.generate_images_pred(inputs, outputs)
+        assert np.array_equal(outputs[("depth", 0)].detach().cpu().numpy(), z["depth"])
+        for f in fids[1:]:
+            assert np.array_equal(outputs[("sample", f)].detach().cpu().numpy(), z["sample_%s" % f])
+            assert rel(outputs[("color", f)], z["color_%s" % f]) < 1e-6
+            rp = vs.compute_reprojection_loss(outputs[("color", f)], inputs[("image", 0)])
+            assert rel(rp, z["rp_%s" % f]) < 1e-5
+        n = noise if cfg["automask"] else None
+        losses = vs.compute_losses(inputs, outputs, n) if fused else vs.compute_losses_unfused(inputs, outputs, n)
+        losses["loss"].backward()
+        assert abs(losses["loss"].item() - float(z["loss"])) <= 1e-5 * float(z["loss"])
+        for s in cfg["scales"]:
+            assert abs(losses["loss/%d" % s].item() - float(z["loss_%d" % s])) <= 1e-5 * float(z["loss_%d" % s])
+        assert rel(disp.grad, z["grad_disp"]) < (1e-5 if fused else 2e-5)
+        for f in fids[1:]:
+            assert rel(poses[f].grad, z["grad_T_%s" % f]) < (1e-5 if fused else 2e-5)
+        if cfg["automask"]:
+            assert np.array_equal(outputs["identity_selection"].cpu().numpy(), z["identity_selection"])
