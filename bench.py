@@ -130,12 +130,26 @@ def cpu_baseline(data, B, H, W, fids, seconds=12.0):
             "kind": "port", "sample": "%d passes of a batch-%d slice of the workload, 1 head, float64 images" % (n, nb)}
 
 
+def pmc_traffic(workload_key):
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, in KB; FETCH_SIZE doubled as gfx950 tallies 128-byte read
+    requests at 64 bytes).  The counters cannot be read from inside this process, so the figure comes
+    from profiles/pmc_traffic.json, written by tools/pmc_summary.py for the same workload; None when
+    that file has no entry for it."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload_key, {}).get("vsl_fused_kernel", {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=12, help="frames per GPU")
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--heads", type=int, default=4)
@@ -143,54 +157,54 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
-    if dist:
-        import torch.distributed as td
-        torch.cuda.set_device(local)
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import mde_amd.dist as D
+    rank, world, local = D.env_rank()
+    if world != max(args.gpus, 1) and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; launch N>1 with torch.distributed.run" % (args.gpus, world),
+              file=sys.stderr)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    D.init("nccl", dev)
 
     B, H, W = args.batch, args.height, args.width
     fids = [0, -1, 1, "s"] if args.stereo else [0, -1, 1]
     S = len(fids) - 1
+    # each rank owns its shard [rank*B, (rank+1)*B) of the global batch: seeded per rank, no exchange
     data, t = build_inputs(B, H, W, fids, args.heads, dev, seed=rank)
     step = LossStep(t, B, H, W, fids, args.heads, dev)
     stream_obj = torch.cuda.current_stream(dev)
     stream = stream_obj.cuda_stream
 
-    def barrier():
+    def fence():
         torch.cuda.synchronize(dev)
-        if dist:
-            td.barrier()
+        D.barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step(stream)
-    barrier()
+    fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream_obj)
     for _ in range(args.steps):
         step(stream)
     ev1.record(stream_obj)
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist:
-        wt = torch.tensor([wall], device=dev, dtype=torch.float64)
-        td.all_reduce(wt, op=td.ReduceOp.MAX)
-        wall = wt.item()
+    fence()
+    wall = D.max_over_ranks(time.perf_counter() - t0, dev)
     gpu_ms = ev0.elapsed_time(ev1)
 
-    # per-kernel timing of the dominant kernel (fused tile kernel) with events around it alone
+    # dominant kernel (the fused tile kernel) alone: HIP events recorded by the library on the launch
+    # stream directly around that launch, averaged over `reps` launches
     import mde_amd._abi as abi
     d0, ws0 = step.descs[0], step.ws[0]
-    reps = 50
-    torch.cuda.synchronize(dev)
+    reps = 100
+    fused_ms = ctypes.c_float(0.0)
+    abi.check(abi.lib.vsl_debug_time_fused(ctypes.byref(d0), ws0.data_ptr(), ws0.numel(), step.losses[0].data_ptr(),
+                                           reps, ctypes.byref(fused_ms), stream))
+    fused_ms = fused_ms.value
+    # whole forward and whole backward of one head (all their kernels), for the per-head breakdown
     k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
     k0.record(stream_obj)
     for _ in range(reps):
         abi.lib.vsl_loss_forward(ctypes.byref(d0), ws0.data_ptr(), ws0.numel(), step.losses[0].data_ptr(),
@@ -209,9 +223,13 @@ def main():
     if rank == 0:
         frames = B * world * args.steps
         ms_per_step = wall * 1e3 / args.steps
-        alg_bytes = BYTES_PER_PX_FWD_BWD[S] * B * H * W            # one head, forward+backward
+        # the fused kernel does the forward AND prepares every gradient in one pass over the pixels, so one
+        # launch carries the whole per-pixel algorithmic traffic of a head (forward reads + backward re-reads
+        # + grad_disp store)
+        alg_bytes = BYTES_PER_PX_FWD_BWD[S] * B * H * W
+        achieved = alg_bytes / (fused_ms * 1e-3) / 1e9
         head_ms = fwd_ms + bwd_ms
-        achieved = alg_bytes / (head_ms * 1e-3) / 1e9
+        key = "%dx%d_b%d_S%d" % (W, H, B, S)
         out = {
             "metric": "training frames/s (loss fwd+bwd) at 640x192 b12",
             "value": frames / wall, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,14 +241,16 @@ def main():
             "gpu_ms_per_step": gpu_ms / args.steps,
             "frames_per_s_per_head": frames * args.heads / wall,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "vsl_fused_kernel (+finalize, grad) per head",
-                         "algorithmic_bytes": alg_bytes, "ms": head_ms, "fwd_ms": fwd_ms, "bwd_ms": bwd_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(key),
+                         "kernel": "vsl_fused_kernel", "kernel_ms": fused_ms, "algorithmic_bytes": alg_bytes,
+                         "head_fwd_ms": fwd_ms, "head_bwd_ms": bwd_ms,
+                         "head_frac": alg_bytes / (head_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(data, B, H, W, fids)
         print(json.dumps(out))
-    if dist:
+    if world > 1:
+        import torch.distributed as td
         td.destroy_process_group()
 
 

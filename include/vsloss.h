@@ -174,6 +174,12 @@ const char* vsl_last_error_string(void);
 /* Diagnostic: workgroups of the fused kernel the runtime expects to fit on one CU for S sources. */
 int vsl_debug_fused_occupancy(int S, int avg_reprojection);
 
+/* Diagnostic / benchmarking: runs vsl_loss_forward `reps` times and returns in *avg_ms (host) the average
+ * duration of the fused tile kernel alone, from HIP events recorded on `stream` directly around that launch.
+ * Synchronises the host; creates and destroys two events. */
+int vsl_debug_time_fused(const vsl_loss_desc* desc, void* workspace, size_t workspace_bytes, float* losses, int reps,
+                         float* avg_ms, void* stream);
+
 /* Library version, e.g. 100 for 0.1.0. */
 int vsl_version(void);
 

@@ -23,7 +23,7 @@ EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", 
            "vsl_project_fwd", "vsl_project_bwd_workspace_bytes", "vsl_project_bwd",
            "vsl_grid_sample_fwd", "vsl_grid_sample_bwd", "vsl_ssim_fwd", "vsl_ssim_bwd",
            "vsl_smooth_workspace_bytes", "vsl_smooth_fwd", "vsl_smooth_bwd",
-           "vsl_debug_fused_occupancy", "vsl_last_error_string", "vsl_version")
+           "vsl_debug_fused_occupancy", "vsl_debug_time_fused", "vsl_last_error_string", "vsl_version")
 
 
 class LossDesc(ctypes.Structure):
@@ -77,6 +77,7 @@ def _load():
         "vsl_smooth_fwd": [P, P, P, P, SZ, I, I, I, I, P],
         "vsl_smooth_bwd": [P, P, P, P, I, I, I, I, P],
         "vsl_debug_fused_occupancy": [I, I],
+        "vsl_debug_time_fused": [P, P, SZ, P, I, P, P],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

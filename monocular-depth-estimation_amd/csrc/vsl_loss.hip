@@ -394,8 +394,12 @@ size_t vsl_loss_workspace_bytes(const vsl_loss_desc* d) {
   return make_layout(d->B, d->H, d->W).total;
 }
 
-int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes, float* losses,
-                     float* identity_selection, void* stream_) {
+}  // extern "C"
+
+namespace {
+// ev0 / ev1 (optional) are recorded on the stream directly around the fused kernel launch
+int forward_impl(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes, float* losses,
+                 float* identity_selection, void* stream_, hipEvent_t ev0, hipEvent_t ev1) {
   if (int rc = check_desc(d)) return rc;
   if (!workspace || !losses) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace and losses must not be NULL");
   if (((uintptr_t)workspace & 255) != 0) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
@@ -455,12 +459,14 @@ int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_b
     }
   }
   int rc = VSL_OK;
+  if (ev0) (void)hipEventRecord(ev0, stream);
   switch (d->S) {
     case 1: rc = launch_fused_s<1>(kp, avg, grid, stream); break;
     case 2: rc = launch_fused_s<2>(kp, avg, grid, stream); break;
     case 3: rc = launch_fused_s<3>(kp, avg, grid, stream); break;
     default: rc = launch_fused_s<4>(kp, avg, grid, stream); break;
   }
+  if (ev1) (void)hipEventRecord(ev1, stream);
   if (rc) return rc;
 
   FinalizeParams fp{};
@@ -487,6 +493,10 @@ int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_b
     return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return VSL_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 #ifdef VSL_STAMPS
 // diagnostic build: copy the phase time stamps of the last fused launch to the host
@@ -515,6 +525,35 @@ int vsl_debug_fused_occupancy(int S, int avg) {
     default: break;
   }
   return n;
+}
+
+int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes, float* losses,
+                     float* identity_selection, void* stream_) {
+  return forward_impl(d, workspace, workspace_bytes, losses, identity_selection, stream_, nullptr, nullptr);
+}
+
+// diagnostic / benchmarking: average duration in ms of the fused tile kernel alone over `reps` forward
+// calls, measured with HIP events recorded on `stream` directly around that launch
+int vsl_debug_time_fused(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes, float* losses, int reps,
+                         float* avg_ms, void* stream_) {
+  if (reps < 1 || !avg_ms) return fail(VSL_ERR_INVALID_ARGUMENT, "reps >= 1 and avg_ms required");
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+    return fail(VSL_ERR_LAUNCH_FAILED, "hipEventCreate failed");
+  double total = 0.0;
+  int rc = VSL_OK;
+  for (int i = 0; i < reps && rc == VSL_OK; ++i) {
+    rc = forward_impl(d, workspace, workspace_bytes, losses, nullptr, stream_, e0, e1);
+    if (rc) break;
+    float ms = 0.0f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+      rc = fail(VSL_ERR_LAUNCH_FAILED, "event timing failed");
+    total += ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = (float)(total / reps);
+  return rc;
 }
 
 int vsl_identity_min(const vsl_loss_desc* d, float* identity_min, void* stream_) {
