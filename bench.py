@@ -99,6 +99,7 @@ def cpu_baseline(data, B, H, W, fids, seconds=12.0):
     """The CPU oracle (pure-PyTorch restatement of the reference path) on a bounded sample:
     batch-2 slices of the same workload, one disparity head, all host threads."""
     from oracle import vsl_oracle as O
+    O.FIXED_ORDER = False       # time the reference's own op sequence: torch.matmul for the small products
     nb = min(2, B)
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     cfg = O.LossConfig(frame_ids=fids, height=H, width=W, automask=True)

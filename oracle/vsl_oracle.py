@@ -64,6 +64,38 @@ class LossConfig:
 
 
 # --------------------------------------------------------------------------
+# the three tiny contractions of the path
+# --------------------------------------------------------------------------
+# The reference calls torch.matmul for K@T, inv_K@pix and P@points (layers.py:168,196-198).
+# In float32 the last bits of a BLAS product depend on the host's BLAS kernels (summation
+# order, use of fused multiply-add), and those bits move the sampling coordinates enough to
+# change float32 gradients at the 1e-5 level.  To give the same numbers on every host the
+# oracle spells the contractions out in the order and rounding the reference produced on the
+# host that generated tests/golden (bit-for-bit, see tests/test_oracle_golden.py):
+#   [B,4,4] @ [B,4,4]  : products and sums rounded separately, k ascending;
+#   [B,m,k] @ [B,k,HW] : first product rounded, then one fused multiply-add per further k.
+# FIXED_ORDER = False switches back to torch.matmul.
+FIXED_ORDER = True
+
+
+def _fma32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """float32 fused multiply-add: the product of two float32 is exact in float64."""
+    return (a.double() * b.double() + c.double()).to(torch.float32)
+
+
+def _contract(A: torch.Tensor, X: torch.Tensor, fused: bool) -> torch.Tensor:
+    """A [B,m,k] @ X [B,k,n] (k <= 4) in a fixed order; other dtypes go to torch.matmul."""
+    if not FIXED_ORDER or A.dtype != torch.float32 or X.dtype != torch.float32:
+        return torch.matmul(A, X)
+    k = A.shape[2]
+    acc = A[:, :, 0:1] * X[:, 0:1, :]
+    for i in range(1, k):
+        a, x = A[:, :, i:i + 1], X[:, i:i + 1, :]
+        acc = _fma32(a, x, acc) if fused else acc + a * x
+    return acc
+
+
+# --------------------------------------------------------------------------
 # geometry
 # --------------------------------------------------------------------------
 def disp_to_depth(disp: torch.Tensor, min_depth: float, max_depth: float):
@@ -74,21 +106,22 @@ def disp_to_depth(disp: torch.Tensor, min_depth: float, max_depth: float):
     return scaled, 1 / scaled
 
 
-def homogeneous_pixels(height: int, width: int, device=None) -> torch.Tensor:
-    """layers.py:149-159 -- [3, H*W] rows (x, y, 1), x fastest, float32."""
+def homogeneous_pixels(height: int, width: int, device=None, dtype=torch.float32) -> torch.Tensor:
+    """layers.py:149-159 -- [3, H*W] rows (x, y, 1), x fastest; float32 in the reference
+    (other dtypes only for high-precision evaluations of the same formulas)."""
     ys, xs = torch.meshgrid(
-        torch.arange(height, dtype=torch.float32, device=device),
-        torch.arange(width, dtype=torch.float32, device=device),
+        torch.arange(height, dtype=dtype, device=device),
+        torch.arange(width, dtype=dtype, device=device),
         indexing="ij",
     )
-    return torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(height * width, device=device)], 0)
+    return torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(height * width, dtype=dtype, device=device)], 0)
 
 
 def backproject(depth: torch.Tensor, inv_K: torch.Tensor) -> torch.Tensor:
     """layers.py:161-174 -- depth [B,1,H,W], inv_K [B,4,4] -> points [B,4,H*W]."""
     b, _, h, w = depth.shape
-    pix = homogeneous_pixels(h, w, depth.device).unsqueeze(0).expand(b, 3, h * w)
-    rays = torch.matmul(inv_K[:, :3, :3], pix)
+    pix = homogeneous_pixels(h, w, depth.device, depth.dtype).unsqueeze(0).expand(b, 3, h * w)
+    rays = _contract(inv_K[:, :3, :3], pix, fused=True)
     pts = depth.reshape(b, 1, -1) * rays
     ones = torch.ones(b, 1, h * w, dtype=pts.dtype, device=pts.device)
     return torch.cat([pts, ones], 1)
@@ -98,8 +131,8 @@ def project(points: torch.Tensor, K: torch.Tensor, T: torch.Tensor,
             height: int, width: int, eps: float = 1e-7) -> torch.Tensor:
     """layers.py:188-202 -- points [B,4,HW] -> normalised grid [B,H,W,2]."""
     b = points.shape[0]
-    P = torch.matmul(K, T)[:, :3, :]
-    cam = torch.matmul(P, points)
+    P = _contract(K, T, fused=False)[:, :3, :]
+    cam = _contract(P, points, fused=True)
     uv = cam[:, :2, :] / (cam[:, 2, :].unsqueeze(1) + eps)
     uv = uv.reshape(b, 2, height, width).permute(0, 2, 3, 1)
     scale = torch.tensor([width - 1, height - 1], dtype=uv.dtype, device=uv.device)

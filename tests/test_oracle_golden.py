@@ -1,7 +1,12 @@
 """The CPU oracle against the fixtures produced by the reference itself.
 
 The oracle uses the same PyTorch primitives in the same order as the reference,
-so agreement is expected to the last bits of float64 / float32."""
+so agreement is expected to the last bits of float64 / float32.  Its three tiny
+matrix products run either through torch.matmul like the reference ("blas") or in
+the spelled-out order that reproduces the fixtures' bits on every host ("fixed",
+the default): forward values are bit-identical in both modes, gradients are
+identical in "blas" mode on the generating host and within 3e-6 in "fixed" mode
+(the backward of the spelled-out products rounds differently)."""
 import numpy as np
 import pytest
 import torch
@@ -18,9 +23,18 @@ def make_cfg(cfg):
         no_ssim=cfg["no_ssim"], warp_scale=0.9 if variant == "distil" else 1.0)
 
 
+@pytest.fixture(params=["fixed", "blas"])
+def contraction_mode(request):
+    old = O.FIXED_ORDER
+    O.FIXED_ORDER = request.param == "fixed"
+    yield request.param
+    O.FIXED_ORDER = old
+
+
 @pytest.mark.parametrize("name", case_names())
-def test_oracle_matches_reference_fixture(name):
+def test_oracle_matches_reference_fixture(name, contraction_mode):
     torch.set_num_threads(1)
+    gtol = 3e-6 if contraction_mode == "fixed" else 1e-6
     cfg, z = load_case(name)
     ocfg = make_cfg(cfg)
     inputs, outputs, disp, poses, noise, fids = build_dicts(cfg, z)
@@ -39,10 +53,10 @@ def test_oracle_matches_reference_fixture(name):
     for s in cfg["scales"]:
         np.testing.assert_allclose(losses["loss/%d" % s].item(), float(z["loss_%d" % s]), rtol=1e-13)
     g = disp.grad.numpy()
-    assert np.linalg.norm(g - z["grad_disp"]) <= 1e-6 * np.linalg.norm(z["grad_disp"])
+    assert np.linalg.norm(g - z["grad_disp"]) <= gtol * np.linalg.norm(z["grad_disp"])
     for f in fids[1:]:
         gt, gr = poses[f].grad.numpy(), z["grad_T_%s" % f]
-        assert np.linalg.norm(gt - gr) <= 1e-6 * np.linalg.norm(gr)
+        assert np.linalg.norm(gt - gr) <= gtol * np.linalg.norm(gr)
 
 
 def test_backproject_points_match_fixture():
