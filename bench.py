@@ -135,14 +135,18 @@ def pmc_traffic(workload_key):
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, in KB; FETCH_SIZE doubled as gfx950 tallies 128-byte read
     requests at 64 bytes).  The counters cannot be read from inside this process, so the figure comes
-    from profiles/pmc_traffic.json, written by tools/pmc_summary.py for the same workload; None when
-    that file has no entry for it."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(workload_key, {}).get("vsl_fused_kernel", {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+    from the newest profiles/r*_pmc_traffic.json (written by tools/pmc_summary.py) that has an entry for
+    the same workload; None when there is none."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                v = json.load(f).get(workload_key, {}).get("vsl_fused_kernel", {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            continue
+        if v is not None:
+            return v
+    return None
 
 
 def main():

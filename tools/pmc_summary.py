@@ -19,7 +19,8 @@ def collect(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            name = row["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
+            name = row["Kernel_Name"].replace("(anonymous namespace)::", "")
+            name = name.split("(")[0].split("<")[0].replace("void ", "").strip()
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return acc
 
