@@ -147,7 +147,7 @@ inline std::pair<torch::Tensor, torch::Tensor> view_synthesis_loss(const torch::
               "vsloss: one pose per source frame, 1..4 source frames");
   std::vector<torch::Tensor> consts{target, K, inv_K};
   for (auto& s : sources) consts.push_back(s);
-  if (noise.defined()) consts.push_back(noise);
+  if (noise.defined() && noise.numel() > 0) consts.push_back(noise);
   auto opt_pose = [&](size_t i) { return i < poses.size() ? std::optional<torch::Tensor>(poses[i]) : std::nullopt; };
   auto out = ViewSynthesisLossFn::apply(disp, poses[0], opt_pose(1), opt_pose(2), opt_pose(3), consts, opt);
   return {out[0], out[1]};

@@ -56,16 +56,33 @@ size_t g_stamp_bytes = 0;
 #define VSL_STAMP(i)
 #endif
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroups i and i+8 share an
+// L2.  The 1-D grid of 8*chunk workgroups is mapped so that every XCD walks one contiguous run of tiles
+// (x fastest, then y, then image): horizontally and vertically adjacent tiles, which share 128-byte lines
+// of the images (a 28-pixel tile row is 112 bytes), then meet in the same L2 at about the same time.
+// Returns the tile's linear index (x fastest), or -1 for the padding workgroups past the last tile.
+__device__ __forceinline__ int swizzled_tile(const KParams& kp, int& b, int& x0, int& y0) {
+  const int tiles_x = (kp.W + kTW - 1) / kTW, tiles_y = (kp.H + kTH - 1) / kTH;
+  const int per_image = tiles_x * tiles_y;
+  const int chunk = (int)(gridDim.x >> 3);
+  const int t = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+  if (t >= per_image * kp.B) return -1;
+  b = t / per_image;
+  const int r = t - b * per_image;
+  const int ty = r / tiles_x;
+  x0 = (r - ty * tiles_x) * kTW;
+  y0 = ty * kTH;
+  return t;
+}
+
 template <int S, bool AVG>
 __global__ __launch_bounds__(kNT, (S <= 2 ? 4 : 3)) void vsl_fused_kernel(const KParams kp) {
   using F = Fused<kTW, kTH, kNT, S, AVG>;
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x;
   typename F::Block bk;
-  bk.b = blockIdx.z;
-  bk.x0 = blockIdx.x * kTW;
-  bk.y0 = blockIdx.y * kTH;
-  const int block_linear = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const int block_linear = swizzled_tile(kp, bk.b, bk.x0, bk.y0);
+  if (block_linear < 0) return;
 
   ThreadState<S> st;
 #ifdef VSL_STAMPS
@@ -115,9 +132,7 @@ __global__ __launch_bounds__(kNT) void vsl_ident_kernel(const KParams kp) {
   using I = Ident<kTW, kTH, kNT, S, AVG>;
   __shared__ __align__(16) float lds[I::LDS_FLOATS];
   typename I::Block bk;
-  bk.b = blockIdx.z;
-  bk.x0 = blockIdx.x * kTW;
-  bk.y0 = blockIdx.y * kTH;
+  if (swizzled_tile(kp, bk.b, bk.x0, bk.y0) < 0) return;
   I::load(kp, bk, threadIdx.x, lds);
   __syncthreads();
   I::compute(kp, bk, threadIdx.x, lds);
@@ -265,6 +280,7 @@ __global__ __launch_bounds__(256) void vsl_grad_kernel(const GradParams gp) {
 // host side
 // --------------------------------------------------------------------------
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+inline unsigned swizzled_grid(int tiles) { return 8u * (unsigned)((tiles + 7) / 8); }  // see swizzled_tile()
 
 struct Layout {
   int tiles_x, tiles_y, tiles_per_image, blocks;
@@ -438,7 +454,7 @@ int forward_impl(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes
   kp.want_grad = want_grad;
   kp.counter = (unsigned int*)(ws + L.off_counter);
 
-  const dim3 grid(L.tiles_x, L.tiles_y, d->B);
+  const dim3 grid(swizzled_grid(L.blocks));
 #ifdef VSL_STAMPS
   {
     const size_t need = (size_t)L.blocks * (kNT / 64) * 16 * sizeof(unsigned long long);
@@ -566,7 +582,7 @@ int vsl_identity_min(const vsl_loss_desc* d, float* identity_min, void* stream_)
   KParams kp = base_params(d);
   kp.idmin = identity_min;
   const Layout L = make_layout(d->B, d->H, d->W);
-  launch_ident(kp, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0, dim3(L.tiles_x, L.tiles_y, d->B), (hipStream_t)stream_);
+  launch_ident(kp, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0, dim3(swizzled_grid(L.blocks)), (hipStream_t)stream_);
   if (hipError_t e = hipGetLastError(); e != hipSuccess)
     return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return VSL_OK;

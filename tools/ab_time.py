@@ -12,6 +12,6 @@ for rnd in range(3):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "10", "--no-cpu-baseline"],
                              env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         d = json.loads(out)
-        res[l].append((d["roofline"]["fwd_ms"] * 1e3, d["ms_per_step"] * 1e3))
+        res[l].append((d["roofline"]["kernel_ms"] * 1e3, d["ms_per_step"] * 1e3))
 for l in libs:
-    print("%-22s fwd_us/head %s   step_us %s" % (l, " ".join("%.1f" % a for a, _ in res[l]), " ".join("%.0f" % b for _, b in res[l])))
+    print("%-22s fused_us %s   step_us %s" % (l, " ".join("%.1f" % a for a, _ in res[l]), " ".join("%.0f" % b for _, b in res[l])))
