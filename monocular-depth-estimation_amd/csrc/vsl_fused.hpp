@@ -138,6 +138,12 @@ struct alignas(8) float2v {
   float x, y;
 };
 
+// two horizontally adjacent texels fetched with one 8-byte load (the address is only 4-byte aligned)
+struct __attribute__((packed, aligned(4))) TexelPair {
+  float lo, hi;
+};
+VSL_DEV TexelPair load_texel_pair(const float* p) { return *reinterpret_cast<const TexelPair*>(p); }
+
 struct Taps {
   int i0, i1;
   float t;
@@ -166,7 +172,8 @@ VSL_DEV Taps axis_taps(float g, int n) {
 // again (they are cache hits) and rebuilds the derivatives.
 struct Chain {
   float tx, ty;  // bilinear fractions
-  int packed;    // bits 0..27 offset of tap (y0,x0) in the image plane, 28: x1 = x0+1, 29: y1 = y0+1,
+  int packed;    // bits 0..27 offset of texel (y0, min(x0, W-2)) in the image plane: the 8 bytes there hold both
+                 // x taps; 28: x1 = x0+1 (else x0 = W-1 and both taps are the second texel), 29: y1 = y0+1,
                  // 30: d/dx passes (0 < ix < W-1), 31: d/dy passes
 };
 
@@ -428,8 +435,10 @@ struct Fused {
     const int ry = tid / ROWP, rx0 = 2 * (tid % ROWP);
     if (ry >= R2H || rx0 >= R2W) return;
     const int H = kp.H, W = kp.W;
-    const size_t HW = (size_t)H * W;
-    const size_t img0 = (size_t)bk.b * 3 * HW;
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    // per-image bases are uniform over the workgroup; per-lane offsets stay unsigned 32-bit
+    const float* dispb = kp.disp + (size_t)bk.b * HW;
+    const float* tgtb = kp.tgt + (size_t)bk.b * 3 * HW;
     const int py = reflect_clamp(bk.y0 - 2 + ry, H);
     const float* ik = lds + OFF_MAT + 12 * S;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
@@ -439,11 +448,11 @@ struct Fused {
     for (int k = 0; k < 2; ++k) {
       const int px = reflect_clamp(bk.x0 - 2 + rx0 + k, W);
       const int p2 = ry * R2W + rx0 + k;
-      const size_t pix = (size_t)py * W + px;
-      const float d = kp.disp[(size_t)bk.b * HW + pix];
+      const unsigned pix = (unsigned)py * (unsigned)W + (unsigned)px;
+      const float d = dispb[pix];
       lds[OFF_DSP + p2] = d;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) lds[OFF_TGT + c * P2 + p2] = kp.tgt[img0 + c * HW + pix];
+      for (int c = 0; c < 3; ++c) lds[OFF_TGT + c * P2 + p2] = (tgtb + (size_t)c * HW)[pix];
 
       // disp_to_depth and the back-projected ray, layers.py:21-25,163-169
       const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
@@ -475,22 +484,26 @@ struct Fused {
         const float gx = VSL_FMUL(VSL_FSUB(VSL_FDIV(u, wm1), 0.5f), 2.0f);
         const float gy = VSL_FMUL(VSL_FSUB(VSL_FDIV(v, hm1), 0.5f), 2.0f);
         const Taps tx = axis_taps(gx, W), ty = axis_taps(gy, H);
-        const float* sp = kp.src[s] + img0;
-        const int o00 = ty.i0 * W + tx.i0, o01 = ty.i0 * W + tx.i1;
-        const int o10 = ty.i1 * W + tx.i0, o11 = ty.i1 * W + tx.i1;
+        const float* sp = kp.src[s] + (size_t)bk.b * 3 * HW;
+        // both x taps of a row come from one 8-byte load at min(x0, W-2)
+        const bool xs = tx.i1 != tx.i0, ys = ty.i1 != ty.i0;
+        const unsigned o0 = (unsigned)ty.i0 * (unsigned)W + (unsigned)(xs ? tx.i0 : W - 2);
+        const unsigned o1 = o0 + (ys ? (unsigned)W : 0u);
         const float w00 = (1.0f - tx.t) * (1.0f - ty.t), w01 = tx.t * (1.0f - ty.t);
         const float w10 = (1.0f - tx.t) * ty.t, w11 = tx.t * ty.t;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float v00 = sp[c * HW + o00], v01 = sp[c * HW + o01];
-          const float v10 = sp[c * HW + o10], v11 = sp[c * HW + o11];
+          const float* pc = sp + (size_t)c * HW;
+          const TexelPair a = load_texel_pair(pc + o0), b = load_texel_pair(pc + o1);
+          const float v00 = xs ? a.lo : a.hi, v01 = a.hi;
+          const float v10 = xs ? b.lo : b.hi, v11 = b.hi;
           lds[OFF_WRP + (s * 3 + c) * P2 + p2] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
         }
         Chain& ch = st.ch[k][s];
         ch.tx = tx.t;
         ch.ty = ty.t;
-        ch.packed = o00 | ((tx.i1 != tx.i0) << 28) | ((ty.i1 != ty.i0) << 29) | ((tx.live != 0.0f) << 30) |
-                    ((ty.live != 0.0f) << 31);
+        ch.packed = (int)(o0 | ((unsigned)xs << 28) | ((unsigned)ys << 29) | ((unsigned)(tx.live != 0.0f) << 30) |
+                          ((unsigned)(ty.live != 0.0f) << 31));
       }
     }
   }
@@ -661,16 +674,18 @@ struct Fused {
         float tv[2][3][4];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const int pk = st.ch[k][s].packed;
-          const int o00 = pk & 0x0FFFFFFF;
-          const int dxo = (pk >> 28) & 1, dyo = ((pk >> 29) & 1) * W;
+          const unsigned pk = (unsigned)st.ch[k][s].packed;
+          const unsigned o0 = pk & 0x0FFFFFFFu;
+          const bool xs = (pk >> 28) & 1u;
+          const unsigned o1 = o0 + (((pk >> 29) & 1u) ? (unsigned)W : 0u);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const float* sp = kp.src[s] + ((size_t)bk.b * 3 + c) * HW + o00;
-            tv[k][c][0] = sp[0];
-            tv[k][c][1] = sp[dxo];
-            tv[k][c][2] = sp[dyo];
-            tv[k][c][3] = sp[dyo + dxo];
+            const float* pc = kp.src[s] + ((size_t)bk.b * 3 + c) * HW;
+            const TexelPair a = load_texel_pair(pc + o0), b = load_texel_pair(pc + o1);
+            tv[k][c][0] = xs ? a.lo : a.hi;
+            tv[k][c][1] = a.hi;
+            tv[k][c][2] = xs ? b.lo : b.hi;
+            tv[k][c][3] = b.hi;
           }
         }
         float g[2][3];  // d L / d warped_c of both pixels
