@@ -49,7 +49,7 @@ class LossStep:
         srcs = fids[1:]
         S = len(srcs)
         self.descs, self.ws, self.losses, self.gdisp, self.gT, self.gT_ptrs = [], [], [], [], [], []
-        self.ident = torch.empty(B, H, W, device=dev)
+        self.ident = [torch.empty(B, H, W, device=dev) for _ in range(heads)]   # identity_selection per head
         # identity-reprojection minimum: depends on the images only, computed once per step
         # and shared by every disparity head of the batch
         self.idmin = torch.empty(B, H, W, device=dev) if automask else None
@@ -83,16 +83,34 @@ class LossStep:
             self.gT.append(gts)
             self.gT_ptrs.append(ptrs)
 
-    def __call__(self, stream):
+    def enable_streams(self, n):
+        """Run the heads on n side streams (they are independent once the identity minimum exists): the tail of
+        one head's tile kernel, its 12-workgroup finalize kernel and its gradient kernel then overlap with the
+        tile kernel of another head instead of leaving CUs idle."""
+        self.side = [torch.cuda.Stream(device=self.dev) for _ in range(n)]
+        self.ev_fork = torch.cuda.Event()
+        self.ev_join = [torch.cuda.Event() for _ in range(n)]
+
+    def __call__(self, stream, stream_obj=None):
         abi = self.abi
         if self.idmin is not None:
             abi.check(abi.lib.vsl_identity_min(ctypes.byref(self.descs[0]), self.idmin.data_ptr(), stream))
+        side = getattr(self, "side", None)
+        if side:
+            self.ev_fork.record(stream_obj)
+            for s in side:
+                s.wait_event(self.ev_fork)
         for h, d in enumerate(self.descs):
             ws = self.ws[h]
+            st = side[h % len(side)].cuda_stream if side else stream
             abi.check(abi.lib.vsl_loss_forward(ctypes.byref(d), ws.data_ptr(), ws.numel(), self.losses[h].data_ptr(),
-                                               self.ident.data_ptr(), stream))
+                                               self.ident[h].data_ptr(), st))
             abi.check(abi.lib.vsl_loss_backward(ctypes.byref(d), ws.data_ptr(), ws.numel(), None,
-                                                self.gdisp[h].data_ptr(), self.gT_ptrs[h], stream))
+                                                self.gdisp[h].data_ptr(), self.gT_ptrs[h], st))
+        if side:
+            for s, e in zip(side, self.ev_join):
+                e.record(s)
+                stream_obj.wait_event(e)
 
 
 def cpu_baseline(data, B, H, W, fids, seconds=12.0):
@@ -158,6 +176,7 @@ def main():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--heads", type=int, default=4)
+    ap.add_argument("--streams", type=int, default=4, help="side streams the heads are spread over (0: one stream)")
     ap.add_argument("--stereo", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -179,6 +198,8 @@ def main():
     step = LossStep(t, B, H, W, fids, args.heads, dev)
     stream_obj = torch.cuda.current_stream(dev)
     stream = stream_obj.cuda_stream
+    if args.streams > 0 and args.heads > 1:
+        step.enable_streams(min(args.streams, args.heads))
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -186,13 +207,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step(stream)
+        step(stream, stream_obj)
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream_obj)
     for _ in range(args.steps):
-        step(stream)
+        step(stream, stream_obj)
     ev1.record(stream_obj)
     fence()
     wall = D.max_over_ranks(time.perf_counter() - t0, dev)
@@ -213,7 +234,7 @@ def main():
     k0.record(stream_obj)
     for _ in range(reps):
         abi.lib.vsl_loss_forward(ctypes.byref(d0), ws0.data_ptr(), ws0.numel(), step.losses[0].data_ptr(),
-                                 step.ident.data_ptr(), stream)
+                                 step.ident[0].data_ptr(), stream)
     k1.record(stream_obj)
     torch.cuda.synchronize(dev)
     fwd_ms = k0.elapsed_time(k1) / reps
@@ -242,7 +263,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d b%d per GPU, frame_ids %s, automask, %d distinct full-res disparity heads "
                                    "(scales 0..%d), fused fwd+bwd through the C-ABI" % (W, H, B, fids, args.heads, args.heads - 1),
-                       "global_batch": B * world, "heads": args.heads},
+                       "global_batch": B * world, "heads": args.heads,
+                       "streams": len(getattr(step, "side", [])) or 1},
             "gpu_ms_per_step": gpu_ms / args.steps,
             "frames_per_s_per_head": frames * args.heads / wall,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -56,6 +56,17 @@
 namespace vsl {
 
 constexpr int kMaxSrc = 4;
+// Tile geometry shared by the HIP kernels and the CPU test build.  A workgroup owns a kTileW x TH tile and has
+// one thread per horizontal pixel pair of the tile grown by 2: 16 * (TH + 4) threads.  VSL_TILE_H selects the
+// tile height of the two-source configuration; 12 (four 4-wave workgroups per CU) measured as fast as 28 (two
+// 8-wave workgroups per CU, 14 % less halo work but longer barrier waits).  The configurations with more LDS
+// planes always use 12 so that their planes fit.
+#ifndef VSL_TILE_H
+#define VSL_TILE_H 12
+#endif
+constexpr int kTileW = 28, kIdentTileH = 12;
+constexpr int fused_tile_h(int S, bool avg) { return (S <= 2 && !avg) ? VSL_TILE_H : 12; }
+constexpr int tile_threads(int th) { return 16 * (th + 4); }
 constexpr float kC1 = 0.01f * 0.01f;
 constexpr float kC2 = 0.03f * 0.03f;
 
@@ -647,6 +658,83 @@ struct Fused {
       const float* ikm = lds + OFF_MAT + 12 * S;
       const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
 
+      float gD[2] = {0.0f, 0.0f};
+      float gcs[S][2][3];  // d L / d cam of (source, pixel); the 3x4 projection gradient is built from it at the end
+
+      // ---- d L / d warped_c of both pixels for every source: 3x3 gather of the winners' coefficients ----
+      // Every coefficient plane is read once; its window is split between the sources by 0/1 masks of the
+      // selection plane (x the row fold on border tiles).  Column sums first, then the two overlapping
+      // windows of the pixel pair.
+      float g[S][2][3];
+      {
+        float mf[S][3][4];
+        {
+          float sw[3][4];
+          load_win(sel, qb, R1W, sw);
+#pragma unroll
+          for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) mf[s][i][j] = AVG ? (float)(sw[i][j] > 0.0f) : (float)(sw[i][j] == (float)s);
+        }
+        // (row 1 of the masks is never folded, so mf[s][1][1 + k] stays the mask of the pixel's own window)
+        if (border) {
+#pragma unroll
+          for (int s = 0; s < (AVG ? 1 : S); ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              mf[s][0][j] *= fy[0];
+              mf[s][2][j] *= fy[2];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float xv[S][2], yv[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            yv[k] = lds[OFF_TGT + c * P2 + p2 + k];
+#pragma unroll
+            for (int s = 0; s < S; ++s) xv[s][k] = lds[OFF_WRP + (s * 3 + c) * P2 + p2 + k];
+          }
+          float gs[S][2];  // sum A + x sum B + y sum G
+#pragma unroll
+          for (int s = 0; s < S; ++s) gs[s][0] = gs[s][1] = 0.0f;
+          if (!kp.no_ssim) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              float cw[3][4];
+              if (!AVG) load_win(coef + (c * 3 + e) * P1, qb, R1W, cw);
+#pragma unroll
+              for (int s = 0; s < S; ++s) {
+                if (AVG) load_win(coef + (s * 9 + c * 3 + e) * P1, qb, R1W, cw);
+                const int ms = AVG ? 0 : s;  // avg_reprojection: one mask (warped beats identity) for all sources
+                float col[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  col[j] = fmaf(mf[ms][2][j], cw[2][j], fmaf(mf[ms][1][j], cw[1][j], mf[ms][0][j] * cw[0][j]));
+                float a2[2];
+                if (!border) {
+                  two_windows(col, a2);
+                } else {
+#pragma unroll
+                  for (int k = 0; k < 2; ++k) a2[k] = fmaf(fxm[k][0], col[k], fmaf(fxm[k][2], col[k + 2], col[k + 1]));
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                  gs[s][k] = (e == 0) ? a2[k] : fmaf(a2[k], (e == 1) ? xv[s][k] : yv[k], gs[s][k]);
+              }
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              g[s][k][c] = kp.cst_ssim * gs[s][k] - kp.cst_l1 * mf[AVG ? 0 : s][1][1 + k] * sgn(yv[k] - xv[s][k]);
+          VSL_SCHED_FENCE();
+        }
+      }
+
       float D[2], r[2][3];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -657,20 +745,9 @@ struct Fused {
 #pragma unroll
         for (int i = 0; i < 3; ++i) r[k][i] = fmaf(ikm[i * 3 + 2], 1.0f, fmaf(ikm[i * 3 + 1], fyv, ikm[i * 3 + 0] * fx));
       }
-      float gD[2] = {0.0f, 0.0f};
-      float gcs[S][2][3];  // d L / d cam of (source, pixel); the 3x4 projection gradient is built from it at the end
-
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        // 0/1 mask of the window positions whose winner is source s
-        float msk[3][4];
-        load_win(sel, qb, R1W, msk);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) msk[i][j] = AVG ? (float)(msk[i][j] > 0.0f) : (float)(msk[i][j] == (float)s);
-        // fetch the bilinear taps of both pixels again (cache hits); they are consumed after the
-        // coefficient gather, which hides their latency
+        // fetch the bilinear taps of both pixels again (cache hits)
         float tv[2][3][4];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -688,45 +765,6 @@ struct Fused {
             tv[k][c][3] = b.hi;
           }
         }
-        float g[2][3];  // d L / d warped_c of both pixels
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float acc[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-          if (!kp.no_ssim) {
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-              float cw[3][4];
-              load_win(coef + ((AVG ? s * 9 : 0) + c * 3 + e) * P1, qb, R1W, cw);
-#pragma unroll
-              for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cw[i][j] *= msk[i][j];
-              if (!border) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                  const float mid = cw[i][1] + cw[i][2];
-                  acc[0][e] += mid + cw[i][0];
-                  acc[1][e] += mid + cw[i][3];
-                }
-              } else {
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                  for (int i = 0; i < 3; ++i) {
-                    const float row = fmaf(fxm[k][0], cw[i][k], fmaf(fxm[k][2], cw[i][k + 2], cw[i][k + 1]));
-                    acc[k][e] = fmaf(fy[i], row, acc[k][e]);
-                  }
-              }
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const float x = lds[OFF_WRP + (s * 3 + c) * P2 + p2 + k];
-            const float y = lds[OFF_TGT + c * P2 + p2 + k];
-            g[k][c] = kp.cst_ssim * (acc[k][0] + acc[k][1] * x + acc[k][2] * y) - kp.cst_l1 * msk[1][1 + k] * sgn(y - x);
-          }
-          VSL_SCHED_FENCE();
-        }
         // tap derivatives d warped_c / d ix, d iy (zero outside the clip range) and the chain to (ix, iy)
         float gix[2] = {0.0f, 0.0f}, giy[2] = {0.0f, 0.0f};
 #pragma unroll
@@ -738,8 +776,8 @@ struct Fused {
             const float v00 = tv[k][c][0], v01 = tv[k][c][1], v10 = tv[k][c][2], v11 = tv[k][c][3];
             const float dpx = (1.0f - ch.ty) * (v01 - v00) + ch.ty * (v11 - v10);
             const float dpy = (1.0f - ch.tx) * (v10 - v00) + ch.tx * (v11 - v01);
-            gix[k] = fmaf(g[k][c], dpx, gix[k]);
-            giy[k] = fmaf(g[k][c], dpy, giy[k]);
+            gix[k] = fmaf(g[s][k][c], dpx, gix[k]);
+            giy[k] = fmaf(g[s][k][c], dpy, giy[k]);
           }
           gix[k] *= lx;
           giy[k] *= ly;

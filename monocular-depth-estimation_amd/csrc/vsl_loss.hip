@@ -29,7 +29,10 @@ namespace {
 using namespace vsl;
 using vsl_err::fail;
 
-constexpr int kTW = 28, kTH = 12, kNT = 256;
+constexpr int kTW = kTileW;
+constexpr int kIdTH = kIdentTileH, kIdNT = tile_threads(kIdentTileH);
+// resident workgroups per CU the fused kernel is compiled for (16 waves per CU with two sources, 12 with more)
+constexpr int fused_blocks_per_cu(int S, int nt) { return (S <= 2 ? 1024 : 768) / nt; }
 
 #ifdef VSL_STAMPS
 unsigned long long* g_stamps = nullptr;
@@ -50,7 +53,7 @@ size_t g_stamp_bytes = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     if ((threadIdx.x & 63) == 0)                                                                \
-      kp.stamps[((size_t)block_linear * (kNT / 64) + (threadIdx.x >> 6)) * 16 + (i)] = t_;      \
+      kp.stamps[((size_t)block_linear * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_;      \
   } while (0)
 #else
 #define VSL_STAMP(i)
@@ -61,8 +64,9 @@ size_t g_stamp_bytes = 0;
 // (x fastest, then y, then image): horizontally and vertically adjacent tiles, which share 128-byte lines
 // of the images (a 28-pixel tile row is 112 bytes), then meet in the same L2 at about the same time.
 // Returns the tile's linear index (x fastest), or -1 for the padding workgroups past the last tile.
+template <int TH>
 __device__ __forceinline__ int swizzled_tile(const KParams& kp, int& b, int& x0, int& y0) {
-  const int tiles_x = (kp.W + kTW - 1) / kTW, tiles_y = (kp.H + kTH - 1) / kTH;
+  const int tiles_x = (kp.W + kTW - 1) / kTW, tiles_y = (kp.H + TH - 1) / TH;
   const int per_image = tiles_x * tiles_y;
   const int chunk = (int)(gridDim.x >> 3);
   const int t = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
@@ -71,17 +75,19 @@ __device__ __forceinline__ int swizzled_tile(const KParams& kp, int& b, int& x0,
   const int r = t - b * per_image;
   const int ty = r / tiles_x;
   x0 = (r - ty * tiles_x) * kTW;
-  y0 = ty * kTH;
+  y0 = ty * TH;
   return t;
 }
 
 template <int S, bool AVG>
-__global__ __launch_bounds__(kNT, (S <= 2 ? 4 : 3)) void vsl_fused_kernel(const KParams kp) {
-  using F = Fused<kTW, kTH, kNT, S, AVG>;
+__global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG)), fused_blocks_per_cu(S, tile_threads(fused_tile_h(S, AVG))))
+void vsl_fused_kernel(const KParams kp) {
+  constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
+  using F = Fused<kTW, TH, NT, S, AVG>;
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x;
   typename F::Block bk;
-  const int block_linear = swizzled_tile(kp, bk.b, bk.x0, bk.y0);
+  const int block_linear = swizzled_tile<TH>(kp, bk.b, bk.x0, bk.y0);
   if (block_linear < 0) return;
 
   ThreadState<S> st;
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(kNT, (S <= 2 ? 4 : 3)) void vsl_fused_kernel(const 
     unsigned int hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    unsigned long long* o = kp.stamps + ((size_t)block_linear * (kNT / 64) + (threadIdx.x >> 6)) * 16;
+    unsigned long long* o = kp.stamps + ((size_t)block_linear * 8 + (threadIdx.x >> 6)) * 16;
     o[9] = rt;
     o[11] = ((unsigned long long)xcc << 32) | hw;
   }
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(kNT, (S <= 2 ? 4 : 3)) void vsl_fused_kernel(const 
   VSL_STAMP(8);
 #ifdef VSL_STAMPS
   if ((threadIdx.x & 63) == 0)
-    kp.stamps[((size_t)block_linear * (kNT / 64) + (threadIdx.x >> 6)) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+    kp.stamps[((size_t)block_linear * 8 + (threadIdx.x >> 6)) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -128,11 +134,11 @@ __global__ __launch_bounds__(kNT, (S <= 2 ? 4 : 3)) void vsl_fused_kernel(const 
 // identity minimum
 // --------------------------------------------------------------------------
 template <int S, bool AVG>
-__global__ __launch_bounds__(kNT) void vsl_ident_kernel(const KParams kp) {
-  using I = Ident<kTW, kTH, kNT, S, AVG>;
+__global__ __launch_bounds__(kIdNT) void vsl_ident_kernel(const KParams kp) {
+  using I = Ident<kTW, kIdTH, kIdNT, S, AVG>;
   __shared__ __align__(16) float lds[I::LDS_FLOATS];
   typename I::Block bk;
-  if (swizzled_tile(kp, bk.b, bk.x0, bk.y0) < 0) return;
+  if (swizzled_tile<kIdTH>(kp, bk.b, bk.x0, bk.y0) < 0) return;
   I::load(kp, bk, threadIdx.x, lds);
   __syncthreads();
   I::compute(kp, bk, threadIdx.x, lds);
@@ -287,10 +293,14 @@ struct Layout {
   size_t off_partials, off_gphoto, off_gedge, off_idmin, off_img, off_gT, off_c12, off_counter, total;
 };
 
-Layout make_layout(int B, int H, int W) {
+inline int desc_tile_h(const vsl_loss_desc* d) {
+  return fused_tile_h(d->S, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0);
+}
+
+Layout make_layout(int B, int H, int W, int th) {
   Layout L;
   L.tiles_x = (W + kTW - 1) / kTW;
-  L.tiles_y = (H + kTH - 1) / kTH;
+  L.tiles_y = (H + th - 1) / th;
   L.tiles_per_image = L.tiles_x * L.tiles_y;
   L.blocks = L.tiles_per_image * B;
   size_t o = 0;
@@ -334,7 +344,8 @@ int check_desc(const vsl_loss_desc* d) {
 
 template <int S, bool AVG>
 int launch_fused(const KParams& kp, dim3 grid, hipStream_t stream) {
-  using F = Fused<kTW, kTH, kNT, S, AVG>;
+  constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
+  using F = Fused<kTW, TH, NT, S, AVG>;
   constexpr size_t lds_bytes = (size_t)F::LDS_FLOATS * sizeof(float);
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit the 160 KiB LDS of a CU");
   static thread_local bool configured = false;
@@ -348,7 +359,7 @@ int launch_fused(const KParams& kp, dim3 grid, hipStream_t stream) {
 #ifdef VSL_STAMPS
   if (const char* e = getenv("VSL_DEBUG_EXTRA_LDS")) launch_lds += (size_t)atoi(e);  // diagnostic: fewer resident blocks
 #endif
-  hipLaunchKernelGGL((vsl_fused_kernel<S, AVG>), grid, dim3(kNT), launch_lds, stream, kp);
+  hipLaunchKernelGGL((vsl_fused_kernel<S, AVG>), grid, dim3(NT), launch_lds, stream, kp);
   return VSL_OK;
 }
 
@@ -360,9 +371,9 @@ int launch_fused_s(const KParams& kp, bool avg, dim3 grid, hipStream_t stream) {
 template <int S>
 void launch_ident_s(const KParams& kp, bool avg, dim3 grid, hipStream_t stream) {
   if (avg)
-    hipLaunchKernelGGL((vsl_ident_kernel<S, true>), grid, dim3(kNT), 0, stream, kp);
+    hipLaunchKernelGGL((vsl_ident_kernel<S, true>), grid, dim3(kIdNT), 0, stream, kp);
   else
-    hipLaunchKernelGGL((vsl_ident_kernel<S, false>), grid, dim3(kNT), 0, stream, kp);
+    hipLaunchKernelGGL((vsl_ident_kernel<S, false>), grid, dim3(kIdNT), 0, stream, kp);
 }
 
 void launch_ident(const KParams& kp, bool avg, dim3 grid, hipStream_t stream) {
@@ -407,7 +418,7 @@ int vsl_version(void) { return 100; }
 
 size_t vsl_loss_workspace_bytes(const vsl_loss_desc* d) {
   if (!d || d->B < 1 || d->H < 1 || d->W < 1) return 0;
-  return make_layout(d->B, d->H, d->W).total;
+  return make_layout(d->B, d->H, d->W, desc_tile_h(d)).total;
 }
 
 }  // extern "C"
@@ -419,7 +430,7 @@ int forward_impl(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes
   if (int rc = check_desc(d)) return rc;
   if (!workspace || !losses) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace and losses must not be NULL");
   if (((uintptr_t)workspace & 255) != 0) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
-  const Layout L = make_layout(d->B, d->H, d->W);
+  const Layout L = make_layout(d->B, d->H, d->W, desc_tile_h(d));
   if (workspace_bytes < L.total) return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "workspace smaller than vsl_loss_workspace_bytes()");
   hipStream_t stream = (hipStream_t)stream_;
   char* ws = (char*)workspace;
@@ -457,7 +468,7 @@ int forward_impl(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes
   const dim3 grid(swizzled_grid(L.blocks));
 #ifdef VSL_STAMPS
   {
-    const size_t need = (size_t)L.blocks * (kNT / 64) * 16 * sizeof(unsigned long long);
+    const size_t need = (size_t)L.blocks * 8 * 16 * sizeof(unsigned long long);
     if (g_stamp_bytes < need) {
       if (g_stamps) (void)hipFree(g_stamps);
       if (hipMalloc((void**)&g_stamps, need) != hipSuccess) return fail(VSL_ERR_LAUNCH_FAILED, "stamp buffer");
@@ -471,7 +482,7 @@ int forward_impl(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes
       kp.idmin = const_cast<float*>(d->identity_min);
     } else {
       kp.idmin = (float*)(ws + L.off_idmin);
-      launch_ident(kp, avg, grid, stream);
+      launch_ident(kp, avg, dim3(swizzled_grid(make_layout(d->B, d->H, d->W, kIdTH).blocks)), stream);
     }
   }
   int rc = VSL_OK;
@@ -528,18 +539,22 @@ long long vsl_debug_read_stamps(void* host_out, long long max_bytes) {
 // diagnostic: resident workgroups per CU the runtime predicts for the fused kernel
 int vsl_debug_fused_occupancy(int S, int avg) {
   int n = -1;
-  auto q = [&](auto kern, size_t lds) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kNT, lds); };
+  auto q = [&](auto kern, int nt, size_t lds) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, nt, lds); };
+#define VSL_OCC(S_, A_)                                                                     \
+  q(vsl_fused_kernel<S_, A_>, tile_threads(fused_tile_h(S_, A_)),                            \
+    Fused<kTW, fused_tile_h(S_, A_), tile_threads(fused_tile_h(S_, A_)), S_, A_>::LDS_FLOATS * sizeof(float))
   switch (S * 2 + (avg ? 1 : 0)) {
-    case 2: q(vsl_fused_kernel<1, false>, Fused<kTW, kTH, kNT, 1, false>::LDS_FLOATS * 4); break;
-    case 3: q(vsl_fused_kernel<1, true>, Fused<kTW, kTH, kNT, 1, true>::LDS_FLOATS * 4); break;
-    case 4: q(vsl_fused_kernel<2, false>, Fused<kTW, kTH, kNT, 2, false>::LDS_FLOATS * 4); break;
-    case 5: q(vsl_fused_kernel<2, true>, Fused<kTW, kTH, kNT, 2, true>::LDS_FLOATS * 4); break;
-    case 6: q(vsl_fused_kernel<3, false>, Fused<kTW, kTH, kNT, 3, false>::LDS_FLOATS * 4); break;
-    case 7: q(vsl_fused_kernel<3, true>, Fused<kTW, kTH, kNT, 3, true>::LDS_FLOATS * 4); break;
-    case 8: q(vsl_fused_kernel<4, false>, Fused<kTW, kTH, kNT, 4, false>::LDS_FLOATS * 4); break;
-    case 9: q(vsl_fused_kernel<4, true>, Fused<kTW, kTH, kNT, 4, true>::LDS_FLOATS * 4); break;
+    case 2: VSL_OCC(1, false); break;
+    case 3: VSL_OCC(1, true); break;
+    case 4: VSL_OCC(2, false); break;
+    case 5: VSL_OCC(2, true); break;
+    case 6: VSL_OCC(3, false); break;
+    case 7: VSL_OCC(3, true); break;
+    case 8: VSL_OCC(4, false); break;
+    case 9: VSL_OCC(4, true); break;
     default: break;
   }
+#undef VSL_OCC
   return n;
 }
 
@@ -581,7 +596,7 @@ int vsl_identity_min(const vsl_loss_desc* d, float* identity_min, void* stream_)
     if (!d->source[s]) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL source image");
   KParams kp = base_params(d);
   kp.idmin = identity_min;
-  const Layout L = make_layout(d->B, d->H, d->W);
+  const Layout L = make_layout(d->B, d->H, d->W, kIdTH);
   launch_ident(kp, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0, dim3(swizzled_grid(L.blocks)), (hipStream_t)stream_);
   if (hipError_t e = hipGetLastError(); e != hipSuccess)
     return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
@@ -593,7 +608,7 @@ int vsl_loss_backward(const vsl_loss_desc* d, const void* workspace, size_t work
   if (int rc = check_desc(d)) return rc;
   if (d->flags & VSL_FLAG_NO_GRAD) return fail(VSL_ERR_INVALID_ARGUMENT, "forward ran with VSL_FLAG_NO_GRAD");
   if (!workspace) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace must not be NULL");
-  const Layout L = make_layout(d->B, d->H, d->W);
+  const Layout L = make_layout(d->B, d->H, d->W, desc_tile_h(d));
   if (workspace_bytes < L.total) return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "workspace smaller than vsl_loss_workspace_bytes()");
   const char* ws = (const char*)workspace;
   GradParams gp{};

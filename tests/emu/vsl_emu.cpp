@@ -13,10 +13,11 @@
 using namespace vsl;
 
 namespace {
-constexpr int kTW = 28, kTH = 12, kNT = 256;
+constexpr int kTW = kTileW;
 
 template <int S, bool AVG>
 void run_ident(const KParams& kp) {
+  constexpr int kTH = kIdentTileH, kNT = tile_threads(kIdentTileH);
   using I = Ident<kTW, kTH, kNT, S, AVG>;
   const int tx = (kp.W + kTW - 1) / kTW, ty = (kp.H + kTH - 1) / kTH;
   std::vector<float> lds(I::LDS_FLOATS);
@@ -32,6 +33,7 @@ void run_ident(const KParams& kp) {
 
 template <int S, bool AVG>
 void run_tiles(KParams kp) {
+  constexpr int kTH = fused_tile_h(S, AVG), kNT = tile_threads(kTH);
   using F = Fused<kTW, kTH, kNT, S, AVG>;
   if (kp.automask) run_ident<S, AVG>(kp);
   const int tx = (kp.W + kTW - 1) / kTW, ty = (kp.H + kTH - 1) / kTH;
@@ -68,5 +70,5 @@ extern "C" int vsl_emu_tiles(const KParams* kp, int avg) {
 
 extern "C" int vsl_emu_part_stride() { return kPartStride; }
 extern "C" int vsl_emu_tile_w() { return kTW; }
-extern "C" int vsl_emu_tile_h() { return kTH; }
+extern "C" int vsl_emu_tile_h(int S, int avg) { return fused_tile_h(S, avg != 0); }
 extern "C" int vsl_emu_kparams_size() { return (int)sizeof(KParams); }

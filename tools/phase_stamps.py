@@ -17,8 +17,9 @@ stream = torch.cuda.current_stream().cuda_stream
 for _ in range(5):
     step(stream)
 torch.cuda.synchronize()
-blocks = ((W + 27) // 28) * ((H + 11) // 12) * B
-buf = np.zeros((blocks, 4, 16), np.uint64)
+TH = int(os.environ.get('VSL_TILE_H', '28')); NW = (TH + 4) // 4
+blocks = ((W + 27) // 28) * ((H + TH - 1) // TH) * B
+buf = np.zeros((blocks, NW, 16), np.uint64)
 abi.lib.vsl_debug_read_stamps.restype = ctypes.c_longlong
 n = abi.lib.vsl_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_longlong(buf.nbytes))
 print("bytes", n)
@@ -27,9 +28,9 @@ names = ["phase0+bar", "phase1", "bar1", "phase2", "bar2", "phase3", "bar3", "ph
 d = np.diff(s[:, :, :9], axis=2)
 print("clock ticks per wave (mean over blocks), by wave index 0..4")
 for i, nm in enumerate(names):
-    print("%-12s" % nm, " ".join("%8.0f" % d[:, w, i].mean() for w in range(4)), "   all: %8.0f" % d[:, :, i].mean())
+    print("%-12s" % nm, " ".join("%8.0f" % d[:, w, i].mean() for w in range(NW)), "   all: %8.0f" % d[:, :, i].mean())
 tot = (s[:, :, 8] - s[:, :, 0])
-print("total       ", " ".join("%8.0f" % tot[:, w].mean() for w in range(4)))
+print("total       ", " ".join("%8.0f" % tot[:, w].mean() for w in range(NW)))
 # global timeline from the constant-rate counter (100 MHz) and the hardware ids
 rt0 = s[:, :, 9].min(axis=1); rt1 = s[:, :, 10].max(axis=1)
 span = rt1.max() - rt0.min()
