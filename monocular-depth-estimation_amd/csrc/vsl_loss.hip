@@ -69,7 +69,11 @@ __device__ __forceinline__ int swizzled_tile(const KParams& kp, int& b, int& x0,
   const int tiles_x = (kp.W + kTW - 1) / kTW, tiles_y = (kp.H + TH - 1) / TH;
   const int per_image = tiles_x * tiles_y;
   const int chunk = (int)(gridDim.x >> 3);
+#ifdef VSL_NO_SWIZZLE
+  const int t = (int)blockIdx.x;
+#else
   const int t = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+#endif
   if (t >= per_image * kp.B) return -1;
   b = t / per_image;
   const int r = t - b * per_image;
