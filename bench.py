@@ -40,19 +40,24 @@ def build_inputs(B, H, W, fids, heads, dev, seed=0):
 
 
 class LossStep:
-    """Pre-bound C-ABI calls for one step (all heads), no per-step allocation."""
+    """Pre-bound C-ABI calls for one step (all heads), no per-step allocation.  merged=True runs all heads
+    through vsl_loss_forward_heads / vsl_loss_backward_heads (one grid for the tiles of all heads);
+    merged=False issues one vsl_loss_forward / vsl_loss_backward per head."""
 
-    def __init__(self, t, B, H, W, fids, heads, dev, automask=True):
+    def __init__(self, t, B, H, W, fids, heads, dev, automask=True, merged=True):
         import mde_amd._abi as abi
         self.abi = abi
         self.dev = dev
+        self.merged = merged
         srcs = fids[1:]
         S = len(srcs)
+        self.n_heads = heads
         self.descs, self.ws, self.losses, self.gdisp, self.gT, self.gT_ptrs = [], [], [], [], [], []
         self.ident = [torch.empty(B, H, W, device=dev) for _ in range(heads)]   # identity_selection per head
         # identity-reprojection minimum: depends on the images only, computed once per step
         # and shared by every disparity head of the batch
         self.idmin = torch.empty(B, H, W, device=dev) if automask else None
+        self.heads = (abi.Head * heads)()
         for h in range(heads):
             d = abi.LossDesc()
             d.B, d.H, d.W, d.S = B, H, W, S
@@ -82,11 +87,19 @@ class LossStep:
                 ptrs[s] = gts[s].data_ptr()
             self.gT.append(gts)
             self.gT_ptrs.append(ptrs)
+            hd = self.heads[h]
+            hd.disp, hd.workspace, hd.workspace_bytes = d.disp, self.ws[h].data_ptr(), n
+            hd.losses, hd.identity_selection = self.losses[h].data_ptr(), self.ident[h].data_ptr()
+            hd.n_scales = 1
+            hd.scale_weight[0] = d.scale_weight[0]
+            hd.grad_losses, hd.grad_disp = None, self.gdisp[h].data_ptr()
+            for s in range(S):
+                hd.grad_T[s] = gts[s].data_ptr()
 
     def enable_streams(self, n):
-        """Run the heads on n side streams (they are independent once the identity minimum exists): the tail of
-        one head's tile kernel, its 12-workgroup finalize kernel and its gradient kernel then overlap with the
-        tile kernel of another head instead of leaving CUs idle."""
+        """Per-head calls only: run the heads on n side streams (they are independent once the identity
+        minimum exists)."""
+        self.merged = False
         self.side = [torch.cuda.Stream(device=self.dev) for _ in range(n)]
         self.ev_fork = torch.cuda.Event()
         self.ev_join = [torch.cuda.Event() for _ in range(n)]
@@ -95,6 +108,10 @@ class LossStep:
         abi = self.abi
         if self.idmin is not None:
             abi.check(abi.lib.vsl_identity_min(ctypes.byref(self.descs[0]), self.idmin.data_ptr(), stream))
+        if self.merged:
+            abi.check(abi.lib.vsl_loss_forward_heads(ctypes.byref(self.descs[0]), self.heads, self.n_heads, stream))
+            abi.check(abi.lib.vsl_loss_backward_heads(ctypes.byref(self.descs[0]), self.heads, self.n_heads, stream))
+            return
         side = getattr(self, "side", None)
         if side:
             self.ev_fork.record(stream_obj)
@@ -176,8 +193,10 @@ def main():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--heads", type=int, default=4)
+    ap.add_argument("--per-head-calls", action="store_true",
+                    help="one vsl_loss_forward/backward per head instead of the merged *_heads calls")
     ap.add_argument("--streams", type=int, default=0,
-                    help="spread the heads over this many side streams (0: everything on one stream; 2 measured +5 %)")
+                    help="with per-head calls: spread the heads over this many side streams (0: one stream)")
     ap.add_argument("--stereo", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -196,7 +215,7 @@ def main():
     S = len(fids) - 1
     # each rank owns its shard [rank*B, (rank+1)*B) of the global batch: seeded per rank, no exchange
     data, t = build_inputs(B, H, W, fids, args.heads, dev, seed=rank)
-    step = LossStep(t, B, H, W, fids, args.heads, dev)
+    step = LossStep(t, B, H, W, fids, args.heads, dev, merged=not args.per_head_calls)
     stream_obj = torch.cuda.current_stream(dev)
     stream = stream_obj.cuda_stream
     if args.streams > 0 and args.heads > 1:
@@ -221,28 +240,26 @@ def main():
     gpu_ms = ev0.elapsed_time(ev1)
 
     # dominant kernel (the fused tile kernel) alone: HIP events recorded by the library on the launch
-    # stream directly around that launch, averaged over `reps` launches
+    # stream directly around that launch, averaged over `reps` launches of the same call the step makes
     import mde_amd._abi as abi
-    d0, ws0 = step.descs[0], step.ws[0]
+    d0 = step.descs[0]
     reps = 100
+    n_launch_heads = step.n_heads if step.merged else 1
     fused_ms = ctypes.c_float(0.0)
-    abi.check(abi.lib.vsl_debug_time_fused(ctypes.byref(d0), ws0.data_ptr(), ws0.numel(), step.losses[0].data_ptr(),
-                                           reps, ctypes.byref(fused_ms), stream))
+    abi.check(abi.lib.vsl_debug_time_fused(ctypes.byref(d0), step.heads, n_launch_heads, reps, ctypes.byref(fused_ms), stream))
     fused_ms = fused_ms.value
-    # whole forward and whole backward of one head (all their kernels), for the per-head breakdown
+    # whole forward and whole backward call (all their kernels), for the breakdown
     k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
     k0.record(stream_obj)
     for _ in range(reps):
-        abi.lib.vsl_loss_forward(ctypes.byref(d0), ws0.data_ptr(), ws0.numel(), step.losses[0].data_ptr(),
-                                 step.ident[0].data_ptr(), stream)
+        abi.lib.vsl_loss_forward_heads(ctypes.byref(d0), step.heads, n_launch_heads, stream)
     k1.record(stream_obj)
     torch.cuda.synchronize(dev)
     fwd_ms = k0.elapsed_time(k1) / reps
     k0.record(stream_obj)
     for _ in range(reps):
-        abi.lib.vsl_loss_backward(ctypes.byref(d0), ws0.data_ptr(), ws0.numel(), None, step.gdisp[0].data_ptr(),
-                                  step.gT_ptrs[0], stream)
+        abi.lib.vsl_loss_backward_heads(ctypes.byref(d0), step.heads, n_launch_heads, stream)
     k1.record(stream_obj)
     torch.cuda.synchronize(dev)
     bwd_ms = k0.elapsed_time(k1) / reps
@@ -251,28 +268,30 @@ def main():
         frames = B * world * args.steps
         ms_per_step = wall * 1e3 / args.steps
         # the fused kernel does the forward AND prepares every gradient in one pass over the pixels, so one
-        # launch carries the whole per-pixel algorithmic traffic of a head (forward reads + backward re-reads
-        # + grad_disp store)
-        alg_bytes = BYTES_PER_PX_FWD_BWD[S] * B * H * W
+        # launch carries the whole per-pixel algorithmic traffic of a head
+        # launch (forward reads + backward re-reads + grad_disp store), for every head the launch covers
+        alg_bytes = BYTES_PER_PX_FWD_BWD[S] * B * H * W * n_launch_heads
         achieved = alg_bytes / (fused_ms * 1e-3) / 1e9
         head_ms = fwd_ms + bwd_ms
-        key = "%dx%d_b%d_S%d" % (W, H, B, S)
+        key = "%dx%d_b%d_S%d_heads%d" % (W, H, B, S, n_launch_heads)
         out = {
             "metric": "training frames/s (loss fwd+bwd) at 640x192 b12",
             "value": frames / wall, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d b%d per GPU, frame_ids %s, automask, %d distinct full-res disparity heads "
-                                   "(scales 0..%d), fused fwd+bwd through the C-ABI" % (W, H, B, fids, args.heads, args.heads - 1),
+                                   "(scales 0..%d), fused fwd+bwd through the C-ABI, %s" % (
+                                       W, H, B, fids, args.heads, args.heads - 1,
+                                       "all heads in one launch" if step.merged else "one call per head"),
                        "global_batch": B * world, "heads": args.heads,
                        "streams": len(getattr(step, "side", [])) or 1},
             "gpu_ms_per_step": gpu_ms / args.steps,
             "frames_per_s_per_head": frames * args.heads / wall,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(key),
-                         "kernel": "vsl_fused_kernel", "kernel_ms": fused_ms, "algorithmic_bytes": alg_bytes,
-                         "head_fwd_ms": fwd_ms, "head_bwd_ms": bwd_ms,
-                         "head_frac": alg_bytes / (head_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "kernel": "vsl_fused_kernel", "kernel_ms": fused_ms, "heads_per_launch": n_launch_heads,
+                         "algorithmic_bytes": alg_bytes, "forward_call_ms": fwd_ms, "backward_call_ms": bwd_ms,
+                         "frac_whole_call": alg_bytes / (head_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(data, B, H, W, fids)

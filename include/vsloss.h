@@ -32,6 +32,7 @@ extern "C" {
 
 #define VSL_MAX_SOURCES 4
 #define VSL_MAX_SCALES 8
+#define VSL_MAX_HEADS 8
 
 /* flag bits of vsl_loss_desc.flags (Python/options.py:105-135) */
 #define VSL_FLAG_AUTOMASK 1u         /* == not opt.disable_automasking  (Trainer.py:553,587) */
@@ -174,11 +175,38 @@ const char* vsl_last_error_string(void);
 /* Diagnostic: workgroups of the fused kernel the runtime expects to fit on one CU for S sources. */
 int vsl_debug_fused_occupancy(int S, int avg_reprojection);
 
-/* Diagnostic / benchmarking: runs vsl_loss_forward `reps` times and returns in *avg_ms (host) the average
- * duration of the fused tile kernel alone, from HIP events recorded on `stream` directly around that launch.
- * Synchronises the host; creates and destroys two events. */
-int vsl_debug_time_fused(const vsl_loss_desc* desc, void* workspace, size_t workspace_bytes, float* losses, int reps,
-                         float* avg_ms, void* stream);
+/*
+ * Several disparity heads over the SAME images, poses, intrinsics and flags in one call: what a
+ * trainer that feeds a different disparity to every entry of opt.scales runs per step
+ * (the `for scale in self.opt.scales` loops of Python/Trainer.py:424 and :534; the student and
+ * teacher heads of Python/Trainer_distilation.py:1221-1224).  One grid covers the tiles of all
+ * heads, one finalize and one gradient launch serve all of them.  From `desc` the calls read
+ * everything except disp, n_scales and scale_weight, which each head carries itself; with
+ * VSL_FLAG_AUTOMASK and desc->identity_min == NULL the identity minimum is computed once (into
+ * the first head's workspace) and shared.  Results are bit-identical to one
+ * vsl_loss_forward / vsl_loss_backward call per head.
+ */
+typedef struct vsl_head {
+  const float* disp;          /* [B,1,H,W] this head's sigmoid disparity                          */
+  void* workspace;            /* vsl_loss_workspace_bytes(desc) bytes, 256-byte aligned, per head   */
+  size_t workspace_bytes;
+  float* losses;              /* out [VSL_LOSS_SLOTS] (forward)                                    */
+  float* identity_selection;  /* out [B,H,W] or NULL (forward)                                     */
+  int32_t n_scales;                    /* loss slots of this head, 1..VSL_MAX_SCALES               */
+  float scale_weight[VSL_MAX_SCALES];  /* disparity_smoothness / 2**scale (Trainer.py:614)         */
+  const float* grad_losses;   /* in [VSL_LOSS_SLOTS] or NULL = d/d losses[VSL_LOSS_TOTAL] (backward) */
+  float* grad_disp;           /* out [B,1,H,W] or NULL (backward)                                  */
+  float* grad_T[VSL_MAX_SOURCES]; /* out [B,4,4] each or NULL (backward)                           */
+} vsl_head;
+
+int vsl_loss_forward_heads(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, void* stream);
+int vsl_loss_backward_heads(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, void* stream);
+
+/* Diagnostic / benchmarking: runs vsl_loss_forward_heads `reps` times and returns in *avg_ms (host) the
+ * average duration of the fused tile kernel alone, from HIP events recorded on `stream` directly around that
+ * launch.  Synchronises the host; creates and destroys two events. */
+int vsl_debug_time_fused(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, int reps, float* avg_ms,
+                         void* stream);
 
 /* Library version, e.g. 100 for 0.1.0. */
 int vsl_version(void);

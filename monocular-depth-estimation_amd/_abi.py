@@ -14,11 +14,13 @@ LIB_PATH = os.environ.get("VSL_LIBRARY", os.path.join(_HERE, "libvsloss.so"))  #
 
 MAX_SOURCES = 4
 MAX_SCALES = 8
+MAX_HEADS = 8
 FLAG_AUTOMASK, FLAG_AVG_REPROJECTION, FLAG_NO_SSIM, FLAG_NO_GRAD = 1, 2, 4, 8
 LOSS_TOTAL, LOSS_PHOTO, LOSS_SMOOTH, LOSS_SCALE0 = 0, 1, 2, 3
 LOSS_SLOTS = 3 + MAX_SCALES
 
 EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", "vsl_identity_min",
+           "vsl_loss_forward_heads", "vsl_loss_backward_heads",
            "vsl_disp_to_depth_fwd", "vsl_disp_to_depth_bwd", "vsl_backproject_fwd", "vsl_backproject_bwd",
            "vsl_project_fwd", "vsl_project_bwd_workspace_bytes", "vsl_project_bwd",
            "vsl_grid_sample_fwd", "vsl_grid_sample_bwd", "vsl_ssim_fwd", "vsl_ssim_bwd",
@@ -41,6 +43,16 @@ class LossDesc(ctypes.Structure):
     ]
 
 
+class Head(ctypes.Structure):
+    """Mirror of ``vsl_head`` (include/vsloss.h)."""
+    _fields_ = [
+        ("disp", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+        ("losses", ctypes.c_void_p), ("identity_selection", ctypes.c_void_p),
+        ("n_scales", ctypes.c_int32), ("scale_weight", ctypes.c_float * MAX_SCALES),
+        ("grad_losses", ctypes.c_void_p), ("grad_disp", ctypes.c_void_p), ("grad_T", ctypes.c_void_p * MAX_SOURCES),
+    ]
+
+
 class VslError(RuntimeError):
     pass
 
@@ -60,6 +72,13 @@ def _load():
     lib.vsl_loss_backward.argtypes = [ctypes.POINTER(LossDesc), ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.c_void_p]
+    for name in ("vsl_loss_forward_heads", "vsl_loss_backward_heads"):
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.POINTER(LossDesc), ctypes.POINTER(Head), ctypes.c_int, ctypes.c_void_p]
+    lib.vsl_debug_time_fused.restype = ctypes.c_int
+    lib.vsl_debug_time_fused.argtypes = [ctypes.POINTER(LossDesc), ctypes.POINTER(Head), ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]
     lib.vsl_identity_min.restype = ctypes.c_int
     lib.vsl_identity_min.argtypes = [ctypes.POINTER(LossDesc), ctypes.c_void_p, ctypes.c_void_p]
     P, I, F, LL, SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
@@ -77,7 +96,6 @@ def _load():
         "vsl_smooth_fwd": [P, P, P, P, SZ, I, I, I, I, P],
         "vsl_smooth_bwd": [P, P, P, P, I, I, I, I, P],
         "vsl_debug_fused_occupancy": [I, I],
-        "vsl_debug_time_fused": [P, P, SZ, P, I, P, P],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -29,6 +29,7 @@ namespace {
 using namespace vsl;
 using vsl_err::fail;
 
+static_assert(sizeof(vsl_loss_desc) == 208 && sizeof(vsl_head) == 128, "C-ABI struct layout changed");
 constexpr int kTW = kTileW;
 constexpr int kIdTH = kIdentTileH, kIdNT = tile_threads(kIdentTileH);
 // resident workgroups per CU the fused kernel is compiled for (16 waves per CU with two sources, 12 with more)
@@ -65,16 +66,19 @@ size_t g_stamp_bytes = 0;
 // of the images (a 28-pixel tile row is 112 bytes), then meet in the same L2 at about the same time.
 // Returns the tile's linear index (x fastest), or -1 for the padding workgroups past the last tile.
 template <int TH>
-__device__ __forceinline__ int swizzled_tile(const KParams& kp, int& b, int& x0, int& y0) {
+__device__ __forceinline__ int swizzled_tile(const KParams& kp, int n_heads, int& head, int& b, int& x0, int& y0) {
   const int tiles_x = (kp.W + kTW - 1) / kTW, tiles_y = (kp.H + TH - 1) / TH;
   const int per_image = tiles_x * tiles_y;
+  const int per_head = per_image * kp.B;
   const int chunk = (int)(gridDim.x >> 3);
 #ifdef VSL_NO_SWIZZLE
-  const int t = (int)blockIdx.x;
+  int t = (int)blockIdx.x;
 #else
-  const int t = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+  int t = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
 #endif
-  if (t >= per_image * kp.B) return -1;
+  if (t >= per_head * n_heads) return -1;
+  head = t / per_head;
+  t -= head * per_head;
   b = t / per_image;
   const int r = t - b * per_image;
   const int ty = r / tiles_x;
@@ -83,16 +87,39 @@ __device__ __forceinline__ int swizzled_tile(const KParams& kp, int& b, int& x0,
   return t;
 }
 
+// Per-head part of the fused kernel's arguments: several disparity heads over the same images and poses run
+// as one grid (head-major tile order), which fills the CUs better than one launch per head.
+struct HeadArgs {
+  int n_heads;
+  const float* disp[VSL_MAX_HEADS];
+  float* gphoto[VSL_MAX_HEADS];
+  float* gedge[VSL_MAX_HEADS];
+  float* ident_sel[VSL_MAX_HEADS];
+  float* partials[VSL_MAX_HEADS];
+  unsigned int* counter[VSL_MAX_HEADS];
+  float cst_ssim[VSL_MAX_HEADS], cst_l1[VSL_MAX_HEADS];
+};
+
 template <int S, bool AVG>
 __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG)), fused_blocks_per_cu(S, tile_threads(fused_tile_h(S, AVG))))
-void vsl_fused_kernel(const KParams kp) {
+void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
   using F = Fused<kTW, TH, NT, S, AVG>;
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x;
   typename F::Block bk;
-  const int block_linear = swizzled_tile<TH>(kp, bk.b, bk.x0, bk.y0);
+  int head = 0;
+  const int block_linear = swizzled_tile<TH>(kp_in, ha.n_heads, head, bk.b, bk.x0, bk.y0);
   if (block_linear < 0) return;
+  KParams kp = kp_in;  // uniform: the head's pointers and constants replace the placeholders
+  kp.disp = ha.disp[head];
+  kp.gphoto = ha.gphoto[head];
+  kp.gedge = ha.gedge[head];
+  kp.ident_sel = ha.ident_sel[head];
+  kp.partials = ha.partials[head];
+  kp.counter = ha.counter[head];
+  kp.cst_ssim = ha.cst_ssim[head];
+  kp.cst_l1 = ha.cst_l1[head];
 
   ThreadState<S> st;
 #ifdef VSL_STAMPS
@@ -142,7 +169,8 @@ __global__ __launch_bounds__(kIdNT) void vsl_ident_kernel(const KParams kp) {
   using I = Ident<kTW, kIdTH, kIdNT, S, AVG>;
   __shared__ __align__(16) float lds[I::LDS_FLOATS];
   typename I::Block bk;
-  if (swizzled_tile<kIdTH>(kp, bk.b, bk.x0, bk.y0) < 0) return;
+  int head = 0;
+  if (swizzled_tile<kIdTH>(kp, 1, head, bk.b, bk.x0, bk.y0) < 0) return;
   I::load(kp, bk, threadIdx.x, lds);
   __syncthreads();
   I::compute(kp, bk, threadIdx.x, lds);
@@ -151,15 +179,11 @@ __global__ __launch_bounds__(kIdNT) void vsl_ident_kernel(const KParams kp) {
 // --------------------------------------------------------------------------
 // finalize
 // --------------------------------------------------------------------------
-struct FinalizeParams {
-  int B, H, W, S;
-  int tiles_per_image;
+struct FinalizeHead {
   int n_scales;
   float scale_weight[VSL_MAX_SCALES];
   float photo_w, smooth_w;  // weights of the two terms in the total
-  double inv_nx, inv_ny;
   const float* partials;
-  const float* K;
   double* img;        // [B][4]: photo sum, smoothness term, c1, c2
   float* gT;          // [kMaxSrc][B][16]
   float* c12;         // [B][2] float copies of c1, c2 for the gradient kernel
@@ -167,16 +191,26 @@ struct FinalizeParams {
   float* losses;      // [VSL_LOSS_SLOTS]
 };
 
+struct FinalizeParams {
+  int B, H, W, S;
+  int tiles_per_image;
+  double inv_nx, inv_ny;
+  const float* K;
+  FinalizeHead head[VSL_MAX_HEADS];
+};
+
+// grid (B, heads): one workgroup reduces the tile records of one image of one head
 __global__ __launch_bounds__(1024) void vsl_finalize_kernel(const FinalizeParams fp) {
   __shared__ double red[16][64];
   __shared__ double tot[64];
+  const FinalizeHead& fh = fp.head[blockIdx.y];
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int v = tid & 63, r = tid >> 6;  // value index, row group (16 tile records in flight per step)
   const int npart = num_partials(fp.S);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (v < npart) {
-    const float* base = fp.partials + (size_t)b * fp.tiles_per_image * kPartStride + v;
+    const float* base = fh.partials + (size_t)b * fp.tiles_per_image * kPartStride + v;
     const int n = fp.tiles_per_image;
     int t = r;
     for (; t + 48 < n; t += 64) {  // four independent loads per step, fixed association order
@@ -206,37 +240,37 @@ __global__ __launch_bounds__(1024) void vsl_finalize_kernel(const FinalizeParams
     const float* Kb = fp.K + 16 * b;
     double g = 0.0;
     for (int i = 0; i < 3; ++i) g += (double)Kb[i * 4 + k] * tot[4 + 12 * s + i * 4 + j];
-    fp.gT[((size_t)s * fp.B + b) * 16 + (tid % 16)] = (float)g;
+    fh.gT[((size_t)s * fp.B + b) * 16 + (tid % 16)] = (float)g;
   }
   if (tid == 0) {
     const double mean = tot[1] / HW;
     const double me = mean + 1e-7;  // Trainer.py:610
     const double edge = tot[2] * fp.inv_nx + tot[3] * fp.inv_ny;
-    const double c1 = (double)fp.smooth_w / me;
-    const double c2 = (double)fp.smooth_w * edge / (me * me * HW);
-    fp.img[b * 4 + 0] = tot[0];
-    fp.img[b * 4 + 1] = edge / me;
-    fp.c12[b * 2 + 0] = (float)c1;
-    fp.c12[b * 2 + 1] = (float)c2;
-    // publish, then take a ticket; the last image's workgroup assembles the scalars
+    const double c1 = (double)fh.smooth_w / me;
+    const double c2 = (double)fh.smooth_w * edge / (me * me * HW);
+    fh.img[b * 4 + 0] = tot[0];
+    fh.img[b * 4 + 1] = edge / me;
+    fh.c12[b * 2 + 0] = (float)c1;
+    fh.c12[b * 2 + 1] = (float)c2;
+    // publish, then take a ticket; the workgroup of the head's last image assembles the scalars
     __threadfence();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int ticket = atomicAdd(fp.counter, 1u);
+    const unsigned int ticket = atomicAdd(fh.counter, 1u);
     const int last = (ticket == (unsigned int)(fp.B - 1));
     if (last) {
       __threadfence();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       double photo = 0.0, smooth = 0.0;
       for (int i = 0; i < fp.B; ++i) {
-        photo += __hip_atomic_load(&fp.img[i * 4 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        smooth += __hip_atomic_load(&fp.img[i * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        photo += __hip_atomic_load(&fh.img[i * 4 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        smooth += __hip_atomic_load(&fh.img[i * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       photo /= (double)fp.B * HW;
-      fp.losses[VSL_LOSS_TOTAL] = (float)((double)fp.photo_w * photo + (double)fp.smooth_w * smooth);
-      fp.losses[VSL_LOSS_PHOTO] = (float)photo;
-      fp.losses[VSL_LOSS_SMOOTH] = (float)smooth;
+      fh.losses[VSL_LOSS_TOTAL] = (float)((double)fh.photo_w * photo + (double)fh.smooth_w * smooth);
+      fh.losses[VSL_LOSS_PHOTO] = (float)photo;
+      fh.losses[VSL_LOSS_SMOOTH] = (float)smooth;
       for (int i = 0; i < VSL_MAX_SCALES; ++i)
-        fp.losses[VSL_LOSS_SCALE0 + i] = (i < fp.n_scales) ? (float)(photo + (double)fp.scale_weight[i] * smooth) : 0.0f;
+        fh.losses[VSL_LOSS_SCALE0 + i] = (i < fh.n_scales) ? (float)(photo + (double)fh.scale_weight[i] * smooth) : 0.0f;
     }
   }
 }
@@ -244,8 +278,7 @@ __global__ __launch_bounds__(1024) void vsl_finalize_kernel(const FinalizeParams
 // --------------------------------------------------------------------------
 // gradient assembly
 // --------------------------------------------------------------------------
-struct GradParams {
-  int B, HW, S;
+struct GradHead {
   const float* gphoto;
   const float* gedge;
   const float* c12;
@@ -258,31 +291,38 @@ struct GradParams {
   float* grad_T[kMaxSrc];
 };
 
+struct GradParams {
+  int B, HW, S;
+  GradHead head[VSL_MAX_HEADS];
+};
+
+// grid (chunks, B, heads)
 __global__ __launch_bounds__(256) void vsl_grad_kernel(const GradParams gp) {
+  const GradHead& gh = gp.head[blockIdx.z];
   // Every loss slot is a combination of the photometric mean and the smoothness term, so the
   // upstream gradients collapse to one factor for each of the two stored gradient parts.
   float ap = 1.0f, as = 1.0f;
-  if (gp.grad_losses) {
-    const float* g = gp.grad_losses;
-    float wp = g[VSL_LOSS_TOTAL] * gp.photo_w + g[VSL_LOSS_PHOTO];
-    float ws = g[VSL_LOSS_TOTAL] * gp.smooth_w + g[VSL_LOSS_SMOOTH];
-    for (int i = 0; i < gp.n_scales; ++i) {
+  if (gh.grad_losses) {
+    const float* g = gh.grad_losses;
+    float wp = g[VSL_LOSS_TOTAL] * gh.photo_w + g[VSL_LOSS_PHOTO];
+    float ws = g[VSL_LOSS_TOTAL] * gh.smooth_w + g[VSL_LOSS_SMOOTH];
+    for (int i = 0; i < gh.n_scales; ++i) {
       wp += g[VSL_LOSS_SCALE0 + i];
-      ws += g[VSL_LOSS_SCALE0 + i] * gp.scale_weight[i];
+      ws += g[VSL_LOSS_SCALE0 + i] * gh.scale_weight[i];
     }
-    ap = wp / gp.photo_w;
-    as = gp.smooth_w != 0.0f ? ws / gp.smooth_w : 0.0f;
+    ap = wp / gh.photo_w;
+    as = gh.smooth_w != 0.0f ? ws / gh.smooth_w : 0.0f;
   }
   const int b = blockIdx.y;
-  if (gp.grad_disp) {
-    const float c1 = as * gp.c12[b * 2 + 0], c2 = as * gp.c12[b * 2 + 1];
+  if (gh.grad_disp) {
+    const float c1 = as * gh.c12[b * 2 + 0], c2 = as * gh.c12[b * 2 + 1];
     const size_t off = (size_t)b * gp.HW;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < gp.HW; i += gridDim.x * blockDim.x)
-      gp.grad_disp[off + i] = ap * gp.gphoto[off + i] + (c1 * gp.gedge[off + i] - c2);
+      gh.grad_disp[off + i] = ap * gh.gphoto[off + i] + (c1 * gh.gedge[off + i] - c2);
   }
   if (blockIdx.x == 0 && threadIdx.x < gp.S * 16) {
     const int s = threadIdx.x / 16, e = threadIdx.x % 16;
-    if (gp.grad_T[s]) gp.grad_T[s][b * 16 + e] = ap * gp.gT[((size_t)s * gp.B + b) * 16 + e];
+    if (gh.grad_T[s]) gh.grad_T[s][b * 16 + e] = ap * gh.gT[((size_t)s * gp.B + b) * 16 + e];
   }
 }
 
@@ -336,18 +376,16 @@ int check_desc(const vsl_loss_desc* d) {
     return fail(VSL_ERR_INVALID_ARGUMENT, "B*3*H*W must stay below 2^31");
   if ((long long)d->H * d->W >= (1ll << 28)) return fail(VSL_ERR_INVALID_ARGUMENT, "H*W must stay below 2^28");
   if (d->S < 1 || d->S > VSL_MAX_SOURCES) return fail(VSL_ERR_INVALID_ARGUMENT, "S must be 1..VSL_MAX_SOURCES");
-  if (d->n_scales < 1 || d->n_scales > VSL_MAX_SCALES)
-    return fail(VSL_ERR_INVALID_ARGUMENT, "n_scales must be 1..VSL_MAX_SCALES");
   if (!(d->min_depth > 0.0f) || !(d->max_depth > d->min_depth))
     return fail(VSL_ERR_INVALID_ARGUMENT, "need 0 < min_depth < max_depth");
-  if (!d->disp || !d->target || !d->K || !d->inv_K) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL input tensor");
+  if (!d->target || !d->K || !d->inv_K) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL input tensor");
   for (int s = 0; s < d->S; ++s)
     if (!d->source[s] || !d->T[s]) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL source image or pose");
   return VSL_OK;
 }
 
 template <int S, bool AVG>
-int launch_fused(const KParams& kp, dim3 grid, hipStream_t stream) {
+int launch_fused(const KParams& kp, const HeadArgs& ha, dim3 grid, hipStream_t stream) {
   constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
   using F = Fused<kTW, TH, NT, S, AVG>;
   constexpr size_t lds_bytes = (size_t)F::LDS_FLOATS * sizeof(float);
@@ -363,13 +401,13 @@ int launch_fused(const KParams& kp, dim3 grid, hipStream_t stream) {
 #ifdef VSL_STAMPS
   if (const char* e = getenv("VSL_DEBUG_EXTRA_LDS")) launch_lds += (size_t)atoi(e);  // diagnostic: fewer resident blocks
 #endif
-  hipLaunchKernelGGL((vsl_fused_kernel<S, AVG>), grid, dim3(NT), launch_lds, stream, kp);
+  hipLaunchKernelGGL((vsl_fused_kernel<S, AVG>), grid, dim3(NT), launch_lds, stream, kp, ha);
   return VSL_OK;
 }
 
 template <int S>
-int launch_fused_s(const KParams& kp, bool avg, dim3 grid, hipStream_t stream) {
-  return avg ? launch_fused<S, true>(kp, grid, stream) : launch_fused<S, false>(kp, grid, stream);
+int launch_fused_s(const KParams& kp, const HeadArgs& ha, bool avg, dim3 grid, hipStream_t stream) {
+  return avg ? launch_fused<S, true>(kp, ha, grid, stream) : launch_fused<S, false>(kp, ha, grid, stream);
 }
 
 template <int S>
@@ -428,51 +466,93 @@ size_t vsl_loss_workspace_bytes(const vsl_loss_desc* d) {
 }  // extern "C"
 
 namespace {
+
+int check_heads(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, bool backward) {
+  if (!heads || n_heads < 1 || n_heads > VSL_MAX_HEADS) return fail(VSL_ERR_INVALID_ARGUMENT, "need 1..VSL_MAX_HEADS heads");
+  const size_t need = make_layout(d->B, d->H, d->W, desc_tile_h(d)).total;
+  for (int h = 0; h < n_heads; ++h) {
+    const vsl_head& hd = heads[h];
+    if (hd.n_scales < 1 || hd.n_scales > VSL_MAX_SCALES) return fail(VSL_ERR_INVALID_ARGUMENT, "n_scales must be 1..VSL_MAX_SCALES");
+    if (!hd.workspace) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace must not be NULL");
+    if (((uintptr_t)hd.workspace & 255) != 0) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    if (hd.workspace_bytes < need) return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "workspace smaller than vsl_loss_workspace_bytes()");
+    if (!backward && (!hd.disp || !hd.losses)) return fail(VSL_ERR_INVALID_ARGUMENT, "disp and losses must not be NULL");
+  }
+  return VSL_OK;
+}
+
+void head_weights(const vsl_loss_desc* d, const vsl_head& hd, float& photo_w, float& smooth_w) {
+  float smooth_sum = 0.0f;
+  for (int i = 0; i < hd.n_scales; ++i) smooth_sum += hd.scale_weight[i];
+  photo_w = (float)hd.n_scales * d->inv_num_scales;
+  smooth_w = smooth_sum * d->inv_num_scales;
+}
+
 // ev0 / ev1 (optional) are recorded on the stream directly around the fused kernel launch
-int forward_impl(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes, float* losses,
-                 float* identity_selection, void* stream_, hipEvent_t ev0, hipEvent_t ev1) {
+int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, void* stream_, hipEvent_t ev0, hipEvent_t ev1) {
   if (int rc = check_desc(d)) return rc;
-  if (!workspace || !losses) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace and losses must not be NULL");
-  if (((uintptr_t)workspace & 255) != 0) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+  if (int rc = check_heads(d, heads, n_heads, false)) return rc;
   const Layout L = make_layout(d->B, d->H, d->W, desc_tile_h(d));
-  if (workspace_bytes < L.total) return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "workspace smaller than vsl_loss_workspace_bytes()");
   hipStream_t stream = (hipStream_t)stream_;
-  char* ws = (char*)workspace;
 
   const bool avg = (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0;
   const bool automask = (d->flags & VSL_FLAG_AUTOMASK) != 0;
   const bool no_ssim = (d->flags & VSL_FLAG_NO_SSIM) != 0;
   const bool want_grad = (d->flags & VSL_FLAG_NO_GRAD) == 0;
-
-  float smooth_sum = 0.0f;
-  for (int i = 0; i < d->n_scales; ++i) smooth_sum += d->scale_weight[i];
-  const float photo_w = (float)d->n_scales * d->inv_num_scales;
-  const float smooth_w = smooth_sum * d->inv_num_scales;
   const double npix = (double)d->B * d->H * d->W;
 
   KParams kp = base_params(d);
   // python floats: min_disp = 1/max_depth, (max_disp - min_disp), then cast to float32 (layers.py:21-23)
   kp.a_disp = (float)(1.0 / (double)d->max_depth);
   kp.c_disp = (float)(1.0 / (double)d->min_depth - 1.0 / (double)d->max_depth);
-  const double base = (double)d->warp_scale * photo_w / npix / (avg ? (double)d->S : 1.0);
-  kp.cst_ssim = no_ssim ? 0.0f : (float)(base * d->ssim_weight / 27.0);
-  kp.cst_l1 = no_ssim ? (float)(base / 3.0) : (float)(base * d->l1_weight / 3.0);
   kp.inv_nx = (float)(1.0 / ((double)d->B * d->H * (d->W - 1)));
   kp.inv_ny = (float)(1.0 / ((double)d->B * (d->H - 1) * d->W));
-  kp.disp = d->disp;
   kp.K = d->K;
   kp.invK = d->inv_K;
-  kp.gphoto = (float*)(ws + L.off_gphoto);
-  kp.gedge = (float*)(ws + L.off_gedge);
-  kp.ident_sel = identity_selection;
-  kp.partials = (float*)(ws + L.off_partials);
   kp.want_grad = want_grad;
-  kp.counter = (unsigned int*)(ws + L.off_counter);
 
-  const dim3 grid(swizzled_grid(L.blocks));
+  HeadArgs ha{};
+  FinalizeParams fp{};
+  ha.n_heads = n_heads;
+  fp.B = d->B;
+  fp.H = d->H;
+  fp.W = d->W;
+  fp.S = d->S;
+  fp.tiles_per_image = L.tiles_per_image;
+  fp.inv_nx = 1.0 / ((double)d->B * d->H * (d->W - 1));
+  fp.inv_ny = 1.0 / ((double)d->B * (d->H - 1) * d->W);
+  fp.K = d->K;
+  for (int h = 0; h < n_heads; ++h) {
+    const vsl_head& hd = heads[h];
+    char* ws = (char*)hd.workspace;
+    float photo_w, smooth_w;
+    head_weights(d, hd, photo_w, smooth_w);
+    const double base = (double)d->warp_scale * photo_w / npix / (avg ? (double)d->S : 1.0);
+    ha.disp[h] = hd.disp;
+    ha.gphoto[h] = (float*)(ws + L.off_gphoto);
+    ha.gedge[h] = (float*)(ws + L.off_gedge);
+    ha.ident_sel[h] = hd.identity_selection;
+    ha.partials[h] = (float*)(ws + L.off_partials);
+    ha.counter[h] = (unsigned int*)(ws + L.off_counter);
+    ha.cst_ssim[h] = no_ssim ? 0.0f : (float)(base * d->ssim_weight / 27.0);
+    ha.cst_l1[h] = no_ssim ? (float)(base / 3.0) : (float)(base * d->l1_weight / 3.0);
+    FinalizeHead& fh = fp.head[h];
+    fh.n_scales = hd.n_scales;
+    for (int i = 0; i < VSL_MAX_SCALES; ++i) fh.scale_weight[i] = i < hd.n_scales ? hd.scale_weight[i] : 0.0f;
+    fh.photo_w = photo_w;
+    fh.smooth_w = smooth_w;
+    fh.partials = ha.partials[h];
+    fh.img = (double*)(ws + L.off_img);
+    fh.gT = (float*)(ws + L.off_gT);
+    fh.c12 = (float*)(ws + L.off_c12);
+    fh.counter = ha.counter[h];
+    fh.losses = hd.losses;
+  }
+
+  const dim3 grid(swizzled_grid(L.blocks * n_heads));
 #ifdef VSL_STAMPS
   {
-    const size_t need = (size_t)L.blocks * 8 * 16 * sizeof(unsigned long long);
+    const size_t need = (size_t)L.blocks * n_heads * 8 * 16 * sizeof(unsigned long long);
     if (g_stamp_bytes < need) {
       if (g_stamps) (void)hipFree(g_stamps);
       if (hipMalloc((void**)&g_stamps, need) != hipSuccess) return fail(VSL_ERR_LAUNCH_FAILED, "stamp buffer");
@@ -484,45 +564,69 @@ int forward_impl(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes
   if (automask) {
     if (d->identity_min) {
       kp.idmin = const_cast<float*>(d->identity_min);
-    } else {
-      kp.idmin = (float*)(ws + L.off_idmin);
+    } else {  // computed once into the first head's workspace and read by every head
+      kp.idmin = (float*)((char*)heads[0].workspace + L.off_idmin);
       launch_ident(kp, avg, dim3(swizzled_grid(make_layout(d->B, d->H, d->W, kIdTH).blocks)), stream);
     }
   }
   int rc = VSL_OK;
   if (ev0) (void)hipEventRecord(ev0, stream);
   switch (d->S) {
-    case 1: rc = launch_fused_s<1>(kp, avg, grid, stream); break;
-    case 2: rc = launch_fused_s<2>(kp, avg, grid, stream); break;
-    case 3: rc = launch_fused_s<3>(kp, avg, grid, stream); break;
-    default: rc = launch_fused_s<4>(kp, avg, grid, stream); break;
+    case 1: rc = launch_fused_s<1>(kp, ha, avg, grid, stream); break;
+    case 2: rc = launch_fused_s<2>(kp, ha, avg, grid, stream); break;
+    case 3: rc = launch_fused_s<3>(kp, ha, avg, grid, stream); break;
+    default: rc = launch_fused_s<4>(kp, ha, avg, grid, stream); break;
   }
   if (ev1) (void)hipEventRecord(ev1, stream);
   if (rc) return rc;
 
-  FinalizeParams fp{};
-  fp.B = d->B;
-  fp.H = d->H;
-  fp.W = d->W;
-  fp.S = d->S;
-  fp.tiles_per_image = L.tiles_per_image;
-  fp.n_scales = d->n_scales;
-  for (int i = 0; i < VSL_MAX_SCALES; ++i) fp.scale_weight[i] = i < d->n_scales ? d->scale_weight[i] : 0.0f;
-  fp.photo_w = photo_w;
-  fp.smooth_w = smooth_w;
-  fp.inv_nx = 1.0 / ((double)d->B * d->H * (d->W - 1));
-  fp.inv_ny = 1.0 / ((double)d->B * (d->H - 1) * d->W);
-  fp.partials = kp.partials;
-  fp.K = d->K;
-  fp.img = (double*)(ws + L.off_img);
-  fp.gT = (float*)(ws + L.off_gT);
-  fp.c12 = (float*)(ws + L.off_c12);
-  fp.counter = (unsigned int*)(ws + L.off_counter);
-  fp.losses = losses;
-  hipLaunchKernelGGL(vsl_finalize_kernel, dim3(d->B), dim3(1024), 0, stream, fp);
+  hipLaunchKernelGGL(vsl_finalize_kernel, dim3(d->B, n_heads), dim3(1024), 0, stream, fp);
   if (hipError_t e = hipGetLastError(); e != hipSuccess)
     return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return VSL_OK;
+}
+
+int backward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, void* stream_) {
+  if (int rc = check_desc(d)) return rc;
+  if (d->flags & VSL_FLAG_NO_GRAD) return fail(VSL_ERR_INVALID_ARGUMENT, "forward ran with VSL_FLAG_NO_GRAD");
+  if (int rc = check_heads(d, heads, n_heads, true)) return rc;
+  const Layout L = make_layout(d->B, d->H, d->W, desc_tile_h(d));
+  GradParams gp{};
+  gp.B = d->B;
+  gp.HW = d->H * d->W;
+  gp.S = d->S;
+  for (int h = 0; h < n_heads; ++h) {
+    const vsl_head& hd = heads[h];
+    const char* ws = (const char*)hd.workspace;
+    GradHead& gh = gp.head[h];
+    gh.gphoto = (const float*)(ws + L.off_gphoto);
+    gh.gedge = (const float*)(ws + L.off_gedge);
+    gh.c12 = (const float*)(ws + L.off_c12);
+    gh.gT = (const float*)(ws + L.off_gT);
+    gh.grad_losses = hd.grad_losses;
+    gh.n_scales = hd.n_scales;
+    for (int i = 0; i < VSL_MAX_SCALES; ++i) gh.scale_weight[i] = i < hd.n_scales ? hd.scale_weight[i] : 0.0f;
+    head_weights(d, hd, gh.photo_w, gh.smooth_w);
+    gh.grad_disp = hd.grad_disp;
+    for (int s = 0; s < kMaxSrc; ++s) gh.grad_T[s] = s < d->S ? hd.grad_T[s] : nullptr;
+  }
+  int bx = (gp.HW + 255) / 256;
+  if (bx > 512) bx = 512;
+  hipLaunchKernelGGL(vsl_grad_kernel, dim3(bx, d->B, n_heads), dim3(256), 0, (hipStream_t)stream_, gp);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess)
+    return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  return VSL_OK;
+}
+
+// the single-head entry points describe their head inside the descriptor
+vsl_head head_of_desc(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes) {
+  vsl_head hd{};
+  hd.disp = d->disp;
+  hd.workspace = workspace;
+  hd.workspace_bytes = workspace_bytes;
+  hd.n_scales = d->n_scales;
+  for (int i = 0; i < VSL_MAX_SCALES; ++i) hd.scale_weight[i] = d->scale_weight[i];
+  return hd;
 }
 
 }  // namespace
@@ -564,13 +668,27 @@ int vsl_debug_fused_occupancy(int S, int avg) {
 
 int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes, float* losses,
                      float* identity_selection, void* stream_) {
-  return forward_impl(d, workspace, workspace_bytes, losses, identity_selection, stream_, nullptr, nullptr);
+  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
+  vsl_head hd = head_of_desc(d, workspace, workspace_bytes);
+  hd.losses = losses;
+  hd.identity_selection = identity_selection;
+  return forward_impl(d, &hd, 1, stream_, nullptr, nullptr);
+}
+
+int vsl_loss_forward_heads(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, void* stream_) {
+  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
+  return forward_impl(d, heads, n_heads, stream_, nullptr, nullptr);
+}
+
+int vsl_loss_backward_heads(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, void* stream_) {
+  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
+  return backward_impl(d, heads, n_heads, stream_);
 }
 
 // diagnostic / benchmarking: average duration in ms of the fused tile kernel alone over `reps` forward
 // calls, measured with HIP events recorded on `stream` directly around that launch
-int vsl_debug_time_fused(const vsl_loss_desc* d, void* workspace, size_t workspace_bytes, float* losses, int reps,
-                         float* avg_ms, void* stream_) {
+int vsl_debug_time_fused(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, int reps, float* avg_ms, void* stream_) {
+  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
   if (reps < 1 || !avg_ms) return fail(VSL_ERR_INVALID_ARGUMENT, "reps >= 1 and avg_ms required");
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
@@ -578,7 +696,7 @@ int vsl_debug_time_fused(const vsl_loss_desc* d, void* workspace, size_t workspa
   double total = 0.0;
   int rc = VSL_OK;
   for (int i = 0; i < reps && rc == VSL_OK; ++i) {
-    rc = forward_impl(d, workspace, workspace_bytes, losses, nullptr, stream_, e0, e1);
+    rc = forward_impl(d, heads, n_heads, stream_, e0, e1);
     if (rc) break;
     float ms = 0.0f;
     if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
@@ -609,37 +727,12 @@ int vsl_identity_min(const vsl_loss_desc* d, float* identity_min, void* stream_)
 
 int vsl_loss_backward(const vsl_loss_desc* d, const void* workspace, size_t workspace_bytes,
                       const float* grad_losses, float* grad_disp, float* const* grad_T, void* stream_) {
-  if (int rc = check_desc(d)) return rc;
-  if (d->flags & VSL_FLAG_NO_GRAD) return fail(VSL_ERR_INVALID_ARGUMENT, "forward ran with VSL_FLAG_NO_GRAD");
-  if (!workspace) return fail(VSL_ERR_INVALID_ARGUMENT, "workspace must not be NULL");
-  const Layout L = make_layout(d->B, d->H, d->W, desc_tile_h(d));
-  if (workspace_bytes < L.total) return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "workspace smaller than vsl_loss_workspace_bytes()");
-  const char* ws = (const char*)workspace;
-  GradParams gp{};
-  gp.B = d->B;
-  gp.HW = d->H * d->W;
-  gp.S = d->S;
-  gp.gphoto = (const float*)(ws + L.off_gphoto);
-  gp.gedge = (const float*)(ws + L.off_gedge);
-  gp.c12 = (const float*)(ws + L.off_c12);
-  gp.gT = (const float*)(ws + L.off_gT);
-  gp.grad_losses = grad_losses;
-  gp.n_scales = d->n_scales;
-  float smooth_sum = 0.0f;
-  for (int i = 0; i < VSL_MAX_SCALES; ++i) {
-    gp.scale_weight[i] = i < d->n_scales ? d->scale_weight[i] : 0.0f;
-    smooth_sum += gp.scale_weight[i];
-  }
-  gp.photo_w = (float)d->n_scales * d->inv_num_scales;
-  gp.smooth_w = smooth_sum * d->inv_num_scales;
-  gp.grad_disp = grad_disp;
-  for (int s = 0; s < kMaxSrc; ++s) gp.grad_T[s] = (grad_T && s < d->S) ? grad_T[s] : nullptr;
-  int bx = (gp.HW + 255) / 256;
-  if (bx > 512) bx = 512;
-  hipLaunchKernelGGL(vsl_grad_kernel, dim3(bx, d->B), dim3(256), 0, (hipStream_t)stream_, gp);
-  if (hipError_t e = hipGetLastError(); e != hipSuccess)
-    return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
-  return VSL_OK;
+  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
+  vsl_head hd = head_of_desc(d, const_cast<void*>(workspace), workspace_bytes);
+  hd.grad_losses = grad_losses;
+  hd.grad_disp = grad_disp;
+  for (int s = 0; s < VSL_MAX_SOURCES; ++s) hd.grad_T[s] = (grad_T && s < d->S) ? grad_T[s] : nullptr;
+  return backward_impl(d, &hd, 1, stream_);
 }
 
 }  // extern "C"

@@ -125,3 +125,119 @@ def fused_view_synthesis_loss(disp: torch.Tensor, target: torch.Tensor, sources:
                noise=_f32c(noise, "noise") if (noise is not None and automask) else None, seed=int(seed))
     losses, ident = _FusedLossFn.apply(cfg, disp, *poses)
     return losses, (ident if automask else None)
+
+
+class _FusedHeadsFn(torch.autograd.Function):
+    """Several disparity heads over the same images and poses in one launch (vsl_loss_*_heads)."""
+
+    @staticmethod
+    def forward(ctx, cfg, n_heads, *tensors):
+        disps, poses = tensors[:n_heads], tensors[n_heads:]
+        desc = _abi.LossDesc()
+        B, _, H, W = disps[0].shape
+        S = len(poses)
+        desc.B, desc.H, desc.W, desc.S = B, H, W, S
+        desc.flags = cfg["flags"] | (0 if cfg["want_grad"] else _abi.FLAG_NO_GRAD)
+        desc.min_depth, desc.max_depth, desc.eps = cfg["min_depth"], cfg["max_depth"], 1e-7
+        desc.ssim_weight, desc.l1_weight, desc.warp_scale = 0.85, 0.15, cfg["warp_scale"]
+        desc.n_scales, desc.inv_num_scales = 1, cfg["inv_num_scales"]
+        desc.target = cfg["target"].data_ptr()
+        desc.K, desc.inv_K = cfg["K"].data_ptr(), cfg["inv_K"].data_ptr()
+        keep = list(disps) + list(poses) + [cfg["target"], cfg["K"], cfg["inv_K"]] + list(cfg["sources"])
+        for s in range(S):
+            desc.source[s] = cfg["sources"][s].data_ptr()
+            desc.T[s] = poses[s].data_ptr()
+        if cfg["noise"] is not None:
+            desc.noise = cfg["noise"].data_ptr()
+            keep.append(cfg["noise"])
+        desc.seed = cfg["seed"]
+        dev = disps[0].device
+        desc.disp = disps[0].data_ptr()      # only read by the workspace query
+        nbytes = _abi.lib.vsl_loss_workspace_bytes(ctypes.byref(desc))
+        automask = bool(cfg["flags"] & _abi.FLAG_AUTOMASK)
+        heads = (_abi.Head * n_heads)()
+        ws = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(n_heads)]
+        losses = torch.empty(n_heads, _abi.LOSS_SLOTS, dtype=torch.float32, device=dev)
+        ident = torch.empty(n_heads if automask else 0, B, H, W, dtype=torch.float32, device=dev)
+        for h in range(n_heads):
+            hd = heads[h]
+            hd.disp, hd.workspace, hd.workspace_bytes = disps[h].data_ptr(), ws[h].data_ptr(), nbytes
+            hd.losses = losses[h].data_ptr()
+            hd.identity_selection = ident[h].data_ptr() if automask else None
+            sw = cfg["scale_weights"][h]
+            hd.n_scales = len(sw)
+            for i, w in enumerate(sw):
+                hd.scale_weight[i] = w
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(_abi.lib.vsl_loss_forward_heads(ctypes.byref(desc), heads, n_heads, stream))
+        ctx.desc, ctx.heads, ctx.ws, ctx.keep = desc, heads, ws, keep
+        ctx.shape = (B, H, W, S, n_heads)
+        ctx.mark_non_differentiable(ident)
+        return losses, ident
+
+    @staticmethod
+    def backward(ctx, g_losses, _g_ident):
+        B, H, W, S, n_heads = ctx.shape
+        dev = ctx.ws[0].device
+        need = ctx.needs_input_grad  # (cfg, n_heads, disps..., poses...)
+        g_losses = g_losses.contiguous().float()
+        grad_disp = [torch.empty(B, 1, H, W, dtype=torch.float32, device=dev) if need[2 + h] else None
+                     for h in range(n_heads)]
+        want_T = [need[2 + n_heads + s] for s in range(S)]
+        grad_T = torch.empty(n_heads, S, B, 4, 4, dtype=torch.float32, device=dev) if any(want_T) else None
+        for h in range(n_heads):
+            hd = ctx.heads[h]
+            hd.grad_losses = g_losses[h].data_ptr()
+            hd.grad_disp = grad_disp[h].data_ptr() if grad_disp[h] is not None else None
+            for s in range(S):
+                hd.grad_T[s] = grad_T[h, s].data_ptr() if want_T[s] else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _abi.check(_abi.lib.vsl_loss_backward_heads(ctypes.byref(ctx.desc), ctx.heads, n_heads, stream))
+        # every head differentiates the same pose matrices: their gradients add up
+        gT = [grad_T[:, s].sum(0) if want_T[s] else None for s in range(S)]
+        return (None, None) + tuple(grad_disp) + tuple(gT)
+
+
+def fused_view_synthesis_loss_heads(disps: Sequence[torch.Tensor], target: torch.Tensor, sources: Sequence[torch.Tensor],
+                                    K: torch.Tensor, inv_K: torch.Tensor, poses: Sequence[torch.Tensor],
+                                    noise: Optional[torch.Tensor] = None, *, automask: bool = True,
+                                    avg_reprojection: bool = False, no_ssim: bool = False,
+                                    scale_weights: Optional[Sequence[Sequence[float]]] = None,
+                                    inv_num_scales: float = 1.0, warp_scale: float = 1.0, min_depth: float = 0.1,
+                                    max_depth: float = 100.0, seed: int = 0):
+    """``fused_view_synthesis_loss`` for several disparity tensors over the same images and poses in one
+    launch.  ``scale_weights[h]`` are head h's smoothness weights (default: [1e-3 / 2**h]).  Returns
+    ``(losses [n_heads, LOSS_SLOTS], identity_selection [n_heads, B, H, W] or None)``; the result of every
+    head is bit-identical to a separate ``fused_view_synthesis_loss`` call."""
+    n_heads = len(disps)
+    if not 1 <= n_heads <= _abi.MAX_HEADS:
+        raise ValueError("need 1..%d heads" % _abi.MAX_HEADS)
+    S = len(sources)
+    if S < 1 or S > _abi.MAX_SOURCES or len(poses) != S:
+        raise ValueError("need 1..%d sources and one pose per source" % _abi.MAX_SOURCES)
+    B, _, H, W = disps[0].shape
+    for d in disps:
+        if d.dim() != 4 or tuple(d.shape) != (B, 1, H, W):
+            raise ValueError("every disp must be [B,1,H,W] of one shape")
+    for t in [target] + list(sources):
+        if tuple(t.shape) != (B, 3, H, W):
+            raise ValueError("images must be [B,3,H,W] matching disp")
+    if scale_weights is None:
+        scale_weights = [[1e-3 / 2 ** h] for h in range(n_heads)]
+    if len(scale_weights) != n_heads or any(not 1 <= len(w) <= _abi.MAX_SCALES for w in scale_weights):
+        raise ValueError("need 1..%d scale weights for every head" % _abi.MAX_SCALES)
+    n_id = 1 if avg_reprojection else S
+    if noise is not None and automask and tuple(noise.shape) != (B, n_id, H, W):
+        raise ValueError("noise must be [B,%d,H,W]" % n_id)
+    flags = (_abi.FLAG_AUTOMASK if automask else 0) | (_abi.FLAG_AVG_REPROJECTION if avg_reprojection else 0) \
+        | (_abi.FLAG_NO_SSIM if no_ssim else 0)
+    poses = [_f32c(p, "pose") for p in poses]
+    disps = [_f32c(d, "disp") for d in disps]
+    want_grad = torch.is_grad_enabled() and any(t.requires_grad for t in disps + poses)
+    cfg = dict(flags=flags, want_grad=want_grad, min_depth=float(min_depth), max_depth=float(max_depth),
+               warp_scale=float(warp_scale), scale_weights=[[float(w) for w in ws] for ws in scale_weights],
+               inv_num_scales=float(inv_num_scales), target=_f32c(target, "target"),
+               sources=[_f32c(s, "source") for s in sources], K=_f32c(K, "K"), inv_K=_f32c(inv_K, "inv_K"),
+               noise=_f32c(noise, "noise") if (noise is not None and automask) else None, seed=int(seed))
+    losses, ident = _FusedHeadsFn.apply(cfg, n_heads, *disps, *poses)
+    return losses, (ident if automask else None)

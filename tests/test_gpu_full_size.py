@@ -187,3 +187,40 @@ def test_in_kernel_noise_changes_only_rare_ties():
     c = gpu_run(data, fids, noise=False)
     assert abs(a[0][0].item() - b[0][0].item()) < 1e-4 * a[0][0].item()
     assert torch.equal(b[0], c[0]) and torch.equal(b[1], c[1])
+
+
+@pytest.mark.parametrize("shape,fids", [((2, 48, 160), [0, -1, 1]), ((12, 192, 640), [0, -1, 1]), ((2, 40, 70), [0, -1, 1, "s"])])
+def test_merged_heads_equal_separate_calls(shape, fids):
+    """vsl_loss_forward_heads / vsl_loss_backward_heads: four heads in one launch give, bit for bit, the
+    losses, selections and disparity gradients of four separate calls; the pose gradient is the sum over heads."""
+    import mde_amd.synth as synth
+    from mde_amd.ops import fused_view_synthesis_loss, fused_view_synthesis_loss_heads
+    B, H, W = shape
+    n_heads = 4
+    data = synth.make_batch(B, H, W, fids, seed=5, n_heads=n_heads)
+    img = lambda f: data[("image", f)].to(DEV)
+    pose = lambda f: (data["stereo_T"] if f == "s" else data[("cam_T_cam", f)]).to(DEV)
+    noise = data["noise"].to(DEV)
+    sw = [[1e-3 / 2 ** h] for h in range(n_heads)]
+    up = torch.linspace(0.5, 2.0, n_heads * 11, device=DEV).reshape(n_heads, 11)   # some upstream gradient
+
+    disps = [data[("disp", h)].to(DEV).requires_grad_(True) for h in range(n_heads)]
+    poses = [pose(f).requires_grad_(True) for f in fids[1:]]
+    losses, ident = fused_view_synthesis_loss_heads(disps, img(0), [img(f) for f in fids[1:]], data["K"].to(DEV),
+                                                    data["inv_K"].to(DEV), poses, noise, scale_weights=sw)
+    (losses * up).sum().backward()
+
+    gT_sum = [torch.zeros(B, 4, 4, device=DEV) for _ in fids[1:]]
+    for h in range(n_heads):
+        d = data[("disp", h)].to(DEV).requires_grad_(True)
+        ps = [pose(f).requires_grad_(True) for f in fids[1:]]
+        l1, i1 = fused_view_synthesis_loss(d, img(0), [img(f) for f in fids[1:]], data["K"].to(DEV),
+                                           data["inv_K"].to(DEV), ps, noise, scale_weights=sw[h])
+        (l1 * up[h]).sum().backward()
+        assert torch.equal(l1, losses[h]) and torch.equal(i1, ident[h])
+        assert torch.equal(d.grad, disps[h].grad)
+        for s in range(len(ps)):
+            gT_sum[s] += ps[s].grad
+    for s in range(len(poses)):
+        err = float((poses[s].grad - gT_sum[s]).norm() / gT_sum[s].norm())
+        assert err < 1e-6, err
