@@ -8,6 +8,7 @@ hot path consists of, with the same names, dict keys and return values:
     compute_losses(inputs, outputs) -> {"loss/{s}", "loss"}   Trainer.py:518-620
     compute_losses_single(inputs, outputs)                    Trainer_distilation.py:1113-1199
     compute_losses_distillation(inputs, outputs, ...)         Trainer_distilation.py:1208-1330 (0.9 scale)
+    compute_losses_per_scale(inputs, outputs)                 the same loop with one disparity per scale
 
 ``compute_losses`` runs ONE fused kernel pass from the disparity and the poses (it does not
 need ``generate_images_pred`` to have run); ``generate_images_pred`` materialises
@@ -25,7 +26,7 @@ import torch.nn.functional as F
 
 from . import _abi
 from .layers import BackprojectDepth, Project3D, SSIM, disp_to_depth, get_smooth_loss, grid_sample_border
-from .ops import fused_view_synthesis_loss
+from .ops import fused_view_synthesis_loss, fused_view_synthesis_loss_heads
 
 
 class ViewSynthesisLoss:
@@ -94,6 +95,34 @@ class ViewSynthesisLoss:
             outputs["identity_selection"] = ident
         losses = {"loss/{}".format(s): out[_abi.LOSS_SCALE0 + i] for i, s in enumerate(opt.scales)}
         losses["loss"] = out[_abi.LOSS_TOTAL]
+        return losses
+
+    def compute_losses_per_scale(self, inputs: Dict, outputs: Dict, noise: Optional[torch.Tensor] = None,
+                                 photometric_scale: Optional[float] = None) -> Dict[str, torch.Tensor]:
+        """The loop of Trainer.py:524-619 for a trainer that feeds a DIFFERENT disparity to every scale
+        (outputs[("disp", s)], upsampled to full resolution as Trainer.py:431 does) instead of the
+        reference's outputs[("disp", 0)] everywhere: all scales run as heads of one launch.  Same keys."""
+        opt = self.opt
+        srcs = self._sources()
+        disps = []
+        for s in opt.scales:
+            d = outputs[("disp", s)]
+            if tuple(d.shape[2:]) != (opt.height, opt.width):
+                d = F.interpolate(d, [opt.height, opt.width], mode="bilinear", align_corners=False)
+            disps.append(d)
+        automask = not opt.disable_automasking
+        self._step += 1
+        out, ident = fused_view_synthesis_loss_heads(
+            disps, inputs[("image", 0)], [inputs[("image", f)] for f in srcs], inputs["K"], inputs["inv_K"],
+            [self._pose(inputs, outputs, f) for f in srcs], noise,
+            automask=automask, avg_reprojection=opt.avg_reprojection, no_ssim=opt.no_ssim,
+            scale_weights=[[opt.disparity_smoothness / (2 ** s)] for s in opt.scales],
+            warp_scale=self.photometric_scale if photometric_scale is None else photometric_scale,
+            min_depth=opt.min_depth, max_depth=opt.max_depth, seed=self.seed + self._step)
+        if automask:
+            outputs["identity_selection"] = ident[-1]      # the reference keeps the last scale's (Trainer.py:602)
+        losses = {"loss/{}".format(s): out[i, _abi.LOSS_TOTAL] for i, s in enumerate(opt.scales)}
+        losses["loss"] = out[:, _abi.LOSS_TOTAL].sum() / self.num_scales
         return losses
 
     # Trainer_distilation.py:1113-1199 is the same computation

@@ -163,3 +163,23 @@ def test_trainer_surface_matches_reference_fixture(name):
             assert rel(poses[f].grad, z["grad_T_%s" % f]) < (1e-5 if fused else 2e-5)
         if cfg["automask"]:
             assert np.array_equal(outputs["identity_selection"].cpu().numpy(), z["identity_selection"])
+
+
+def test_per_scale_disparities_equal_the_reference_loop_when_all_scales_share_one_disparity():
+    """compute_losses_per_scale with outputs[("disp", s)] = disp for every s reproduces the reference's loop
+    (which reads ("disp", 0) at every scale): same "loss/{s}", same "loss", same gradients."""
+    from mde_amd.trainer_loss import ViewSynthesisLoss
+    cfg, z = load_case("b2_24x80_scales4")
+    inputs, outputs, disp, poses, noise, fids = build_dicts(cfg, z, image_dtype=torch.float64, device=DEV)
+    for s in cfg["scales"]:
+        outputs[("disp", s)] = disp
+    vs = ViewSynthesisLoss(_opt(cfg))
+    losses = vs.compute_losses_per_scale(inputs, outputs, noise)
+    losses["loss"].backward()
+    assert abs(losses["loss"].item() - float(z["loss"])) <= 1e-5 * float(z["loss"])
+    for s in cfg["scales"]:
+        assert abs(losses["loss/%d" % s].item() - float(z["loss_%d" % s])) <= 1e-5 * float(z["loss_%d" % s])
+    assert rel(disp.grad, z["grad_disp"]) < 1e-5
+    for f in fids[1:]:
+        assert rel(poses[f].grad, z["grad_T_%s" % f]) < 1e-5
+    assert np.array_equal(outputs["identity_selection"].cpu().numpy(), z["identity_selection"])
