@@ -739,8 +739,7 @@ struct Fused {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const float d = lds[OFF_DSP + p2 + k];
-        const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
-        D[k] = VSL_FDIV(1.0f, sd);
+        D[k] = fast_rcp(fmaf(kp.c_disp, d, kp.a_disp));  // gradient only: a plain reciprocal is enough
         const float fx = (float)(jx0 + k), fyv = (float)jy;
 #pragma unroll
         for (int i = 0; i < 3; ++i) r[k][i] = fmaf(ikm[i * 3 + 2], 1.0f, fmaf(ikm[i * 3 + 1], fyv, ikm[i * 3 + 0] * fx));

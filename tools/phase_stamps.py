@@ -19,10 +19,11 @@ for _ in range(5):
 torch.cuda.synchronize()
 TH = int(os.environ.get('VSL_TILE_H', '28')); NW = (TH + 4) // 4
 blocks = ((W + 27) // 28) * ((H + TH - 1) // TH) * B
-buf = np.zeros((blocks, NW, 16), np.uint64)
+buf = np.zeros((blocks, 8, 16), np.uint64)      # the library reserves 8 wave slots per workgroup
 abi.lib.vsl_debug_read_stamps.restype = ctypes.c_longlong
 n = abi.lib.vsl_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_longlong(buf.nbytes))
 print("bytes", n)
+buf = buf[:, :NW]
 s = buf.astype(np.int64)
 names = ["phase0+bar", "phase1", "bar1", "phase2", "bar2", "phase3", "bar3", "phase4"]
 d = np.diff(s[:, :, :9], axis=2)
