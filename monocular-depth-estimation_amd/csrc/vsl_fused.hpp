@@ -418,7 +418,12 @@ struct Fused {
   static constexpr int RED_PITCH = NT + 1;
   static constexpr int RED_FLOATS = NPART * RED_PITCH;
   static constexpr int RED_SPLIT = 8;
-  static constexpr int LDS_MAIN = OFF_COEF + COEF_FLOATS;
+  // Tap records of the last two interior rows, handed from the threads that warped them (R2 rows TH, TH+1) to
+  // the threads of R2 rows 0, 1: phase 3 then keeps the last wave (R2 rows TH..TH+3) completely idle instead of
+  // running four half-empty waves.
+  static constexpr int OFF_XFER = OFF_COEF + COEF_FLOATS;
+  static constexpr int XFER_FLOATS = 2 * ROWP * 2 * S * 3;
+  static constexpr int LDS_MAIN = OFF_XFER + XFER_FLOATS;
   static constexpr int RED_TOTAL = RED_FLOATS + NPART * RED_SPLIT;
   static constexpr int LDS_FLOATS = LDS_MAIN > RED_TOTAL ? LDS_MAIN : RED_TOTAL;
 
@@ -515,6 +520,12 @@ struct Fused {
         ch.ty = ty.t;
         ch.packed = (int)(o0 | ((unsigned)xs << 28) | ((unsigned)ys << 29) | ((unsigned)(tx.live != 0.0f) << 30) |
                           ((unsigned)(ty.live != 0.0f) << 31));
+        if (ry >= TH && ry < TH + 2) {
+          float* xf = lds + OFF_XFER + (((ry - TH) * ROWP + tid % ROWP) * 2 + k) * (S * 3) + s * 3;
+          xf[0] = ch.tx;
+          xf[1] = ch.ty;
+          xf[2] = __builtin_bit_cast(float, ch.packed);
+        }
       }
     }
   }
@@ -625,8 +636,25 @@ struct Fused {
     for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
     st.part[0] = st.photo;
     const int H = kp.H, W = kp.W;
-    const int iy = tid / ROWP - 2, ip = tid % ROWP - 1;  // (R2 row, R2 pair) of phase 1 -> interior coordinates
-    if (iy < 0 || iy >= TH || ip < 0 || ip >= TW / 2) return;
+    // (R2 row, R2 pair) of phase 1 -> interior coordinates; the threads of R2 rows 0, 1 (halo in phase 1) take
+    // over the last two interior rows, so that the R2 rows from TH on -- the whole last wave -- stay idle
+    const int row = tid / ROWP, ip = tid % ROWP - 1;
+    if (row >= TH || ip < 0 || ip >= TW / 2) return;
+    const bool remote = row < 2;
+    const int iy = remote ? row + TH - 2 : row - 2;
+    Chain chn[2][S];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        chn[k][s] = st.ch[k][s];
+        if (remote) {
+          const float* xf = lds + OFF_XFER + ((row * ROWP + tid % ROWP) * 2 + k) * (S * 3) + s * 3;
+          chn[k][s].tx = xf[0];
+          chn[k][s].ty = xf[1];
+          chn[k][s].packed = __builtin_bit_cast(int, xf[2]);
+        }
+      }
     const int jy = bk.y0 + iy;
     if (jy >= H) return;
     const int jx0 = bk.x0 + 2 * ip;
@@ -750,7 +778,7 @@ struct Fused {
         float tv[2][3][4];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const unsigned pk = (unsigned)st.ch[k][s].packed;
+          const unsigned pk = (unsigned)chn[k][s].packed;
           const unsigned o0 = pk & 0x0FFFFFFFu;
           const bool xs = (pk >> 28) & 1u;
           const unsigned o1 = o0 + (((pk >> 29) & 1u) ? (unsigned)W : 0u);
@@ -768,7 +796,7 @@ struct Fused {
         float gix[2] = {0.0f, 0.0f}, giy[2] = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const Chain ch = st.ch[k][s];
+          const Chain ch = chn[k][s];
           const float lx = (float)((ch.packed >> 30) & 1), ly = (float)((ch.packed >> 31) & 1);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
