@@ -639,7 +639,11 @@ struct Fused {
     // (R2 row, R2 pair) of phase 1 -> interior coordinates; the threads of R2 rows 0, 1 (halo in phase 1) take
     // over the last two interior rows, so that the R2 rows from TH on -- the whole last wave -- stay idle
     const int row = tid / ROWP, ip = tid % ROWP - 1;
-    if (row >= TH || ip < 0 || ip >= TW / 2) return;
+    if (row >= TH) {
+      phase3_smooth(kp, bk, tid, lds, st);
+      return;
+    }
+    if (ip < 0 || ip >= TW / 2) return;
     const bool remote = row < 2;
     const int iy = remote ? row + TH - 2 : row - 2;
     Chain chn[2][S];
@@ -849,44 +853,59 @@ struct Fused {
         }
     }
 
-    // edge-aware smoothness, layers.py:211-226 with the 1/(mean+1e-7) factor applied later
+    if (kp.want_grad) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (!ok[k]) continue;
-      const int jx = jx0 + k;
-      const int pp = p2 + k;
-      const float d0 = lds[OFF_DSP + pp];
-      float ax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum_c |I - I_neighbour| for right, left, down, up
+      for (int k = 0; k < 2; ++k)
+        if (ok[k]) kp.gphoto[(size_t)bk.b * HW + (size_t)jy * W + jx0 + k] = g_disp[k];
+    }
+  }
+
+  // Edge-aware smoothness of the tile, layers.py:211-226 with the 1/(mean+1e-7) factor applied later.  It needs
+  // only the disparity and target planes, so the wave that has no interior pixels in phase 3 (R2 rows from TH on)
+  // computes it for the whole tile while the other waves do the photometric gradient.
+  static VSL_DEV void phase3_smooth(const KParams& kp, const Block& bk, int tid, const float* lds, ThreadState<S>& st) {
+    const int H = kp.H, W = kp.W;
+    const size_t HW = (size_t)H * W;
+    constexpr int NSM = NT - TH * ROWP;  // threads of the idle rows
+    for (int q = tid - TH * ROWP; q < TH * (TW / 2); q += NSM) {
+      const int iy = q / (TW / 2), ip = q % (TW / 2);
+      const int jy = bk.y0 + iy, jx0 = bk.x0 + 2 * ip;
+      if (jy >= H || jx0 >= W) continue;
+      const int p2 = (2 + iy) * R2W + 2 + 2 * ip;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float* tp = lds + OFF_TGT + c * P2;
-        const float i0 = tp[pp];
-        ax[0] += fabsf(i0 - tp[pp + 1]);
-        ax[1] += fabsf(tp[pp - 1] - i0);
-        ax[2] += fabsf(i0 - tp[pp + R2W]);
-        ax[3] += fabsf(tp[pp - R2W] - i0);
-      }
-      const float dn[4] = {lds[OFF_DSP + pp + 1], lds[OFF_DSP + pp - 1], lds[OFF_DSP + pp + R2W],
-                           lds[OFF_DSP + pp - R2W]};
-      const bool has[4] = {jx + 1 < W, jx > 0, jy + 1 < H, jy > 0};
-      float e = 0.0f;
+      for (int k = 0; k < 2; ++k) {
+        const int jx = jx0 + k;
+        if (jx >= W) continue;
+        const int pp = p2 + k;
+        const float d0 = lds[OFF_DSP + pp];
+        float ax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum_c |I - I_neighbour| for right, left, down, up
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (!has[t]) continue;
-        const float w = VSL_EXP(-ax[t] * (1.0f / 3.0f));
-        const float inv_n = (t < 2) ? kp.inv_nx : kp.inv_ny;
-        // right/down edges are owned by this pixel (first operand), left/up by the neighbour
-        const float diff = (t == 0 || t == 2) ? d0 - dn[t] : dn[t] - d0;
-        const float sg = sgn(diff) * w * inv_n;
-        e += (t == 0 || t == 2) ? sg : -sg;
-        if (t == 0) st.part[2] = fmaf(w, fabsf(diff), st.part[2]);
-        if (t == 2) st.part[3] = fmaf(w, fabsf(diff), st.part[3]);
-      }
-      st.part[1] += d0;
-      const size_t o = (size_t)bk.b * HW + (size_t)jy * W + jx;
-      if (kp.want_grad) {
-        kp.gphoto[o] = g_disp[k];
-        kp.gedge[o] = e;
+        for (int c = 0; c < 3; ++c) {
+          const float* tp = lds + OFF_TGT + c * P2;
+          const float i0 = tp[pp];
+          ax[0] += fabsf(i0 - tp[pp + 1]);
+          ax[1] += fabsf(tp[pp - 1] - i0);
+          ax[2] += fabsf(i0 - tp[pp + R2W]);
+          ax[3] += fabsf(tp[pp - R2W] - i0);
+        }
+        const float dn[4] = {lds[OFF_DSP + pp + 1], lds[OFF_DSP + pp - 1], lds[OFF_DSP + pp + R2W],
+                             lds[OFF_DSP + pp - R2W]};
+        const bool has[4] = {jx + 1 < W, jx > 0, jy + 1 < H, jy > 0};
+        float e = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (!has[t]) continue;
+          const float w = VSL_EXP(-ax[t] * (1.0f / 3.0f));
+          const float inv_n = (t < 2) ? kp.inv_nx : kp.inv_ny;
+          // right/down edges are owned by this pixel (first operand), left/up by the neighbour
+          const float diff = (t == 0 || t == 2) ? d0 - dn[t] : dn[t] - d0;
+          const float sg = sgn(diff) * w * inv_n;
+          e += (t == 0 || t == 2) ? sg : -sg;
+          if (t == 0) st.part[2] = fmaf(w, fabsf(diff), st.part[2]);
+          if (t == 2) st.part[3] = fmaf(w, fabsf(diff), st.part[3]);
+        }
+        st.part[1] += d0;
+        if (kp.want_grad) kp.gedge[(size_t)bk.b * HW + (size_t)jy * W + jx] = e;
       }
     }
   }
