@@ -311,24 +311,30 @@ struct Ident {
   static constexpr int RW = TW + 2, RH = TH + 2, PN = RW * RH;
   static constexpr int ROWP = 16;
   static constexpr int LDS_FLOATS = (3 + 3 * S) * PN;
-  static_assert(TW / 2 <= ROWP && ROWP * TH <= NT && PN % 2 == 0 && TW % 2 == 0, "tile / thread mismatch");
+  static_assert(RW / 2 <= ROWP && ROWP * RH <= NT && PN % 2 == 0 && TW % 2 == 0, "tile / thread mismatch");
 
   struct Block {
     int b, x0, y0;
   };
 
   static VSL_DEV void load(const KParams& kp, const Block& bk, int tid, float* lds) {
-    const size_t HW = (size_t)kp.H * kp.W;
-    const size_t img0 = (size_t)bk.b * 3 * HW;
-    for (int p = tid; p < PN; p += NT) {
-      const int ry = p / RW, rx = p % RW;
-      const int py = reflect_clamp(bk.y0 - 1 + ry, kp.H), px = reflect_clamp(bk.x0 - 1 + rx, kp.W);
-      const size_t pix = (size_t)py * kp.W + px;
+    // one pixel pair of the tile grown by 1 per thread (row = tid / ROWP, pair = tid % ROWP), 32-bit offsets
+    // from uniform plane bases
+    const int ry = tid / ROWP, rx0 = 2 * (tid % ROWP);
+    if (ry >= RH || rx0 >= RW) return;
+    const unsigned HW = (unsigned)kp.H * (unsigned)kp.W;
+    const float* tgtb = kp.tgt + (size_t)bk.b * 3 * HW;
+    const int py = reflect_clamp(bk.y0 - 1 + ry, kp.H);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int px = reflect_clamp(bk.x0 - 1 + rx0 + k, kp.W);
+      const unsigned pix = (unsigned)py * (unsigned)kp.W + (unsigned)px;
+      const int p = ry * RW + rx0 + k;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        lds[c * PN + p] = kp.tgt[img0 + c * HW + pix];
+        lds[c * PN + p] = (tgtb + (size_t)c * HW)[pix];
 #pragma unroll
-        for (int s = 0; s < S; ++s) lds[(3 + s * 3 + c) * PN + p] = kp.src[s][img0 + c * HW + pix];
+        for (int s = 0; s < S; ++s) lds[(3 + s * 3 + c) * PN + p] = (kp.src[s] + ((size_t)bk.b * 3 + c) * HW)[pix];
       }
     }
   }
