@@ -188,8 +188,17 @@ struct Chain {
                  // 30: d/dx passes (0 < ix < W-1), 31: d/dy passes
 };
 
+// Projection matrices P = (K T)[:3,:] of every source and the 3x3 part of inv_K: the same for every thread of a
+// workgroup, so on the GPU they live in scalar registers (one lane computes each entry, v_readlane broadcasts).
+template <int S>
+struct Mats {
+  float P[S][12];
+  float ik[9];
+};
+
 template <int S>
 struct ThreadState {
+  Mats<S> m;
   Chain ch[2][S];
   float photo;                  // sum of the selected photometric error over this thread's interior pixels
   float part[num_partials(S)];  // filled at the end of phase 3
@@ -414,9 +423,7 @@ struct Fused {
   static_assert(P2 % 2 == 0 && P1 % 2 == 0, "planes must keep 8-byte alignment");
 
   // LDS layout in floats
-  static constexpr int OFF_MAT = 0;  // 12*S projection entries + 9 inv_K entries
-  static constexpr int MAT_FLOATS = ((12 * S + 9 + 3) / 4) * 4;
-  static constexpr int OFF_TGT = OFF_MAT + MAT_FLOATS;  // 3 planes over R2
+  static constexpr int OFF_TGT = 0;  // 3 planes over R2
   static constexpr int OFF_WRP = OFF_TGT + 3 * P2;      // S*3 planes over R2
   static constexpr int OFF_DSP = OFF_WRP + S * 3 * P2;  // 1 plane over R2
   static constexpr int OFF_COEF = OFF_DSP + P2;         // NSET*9 coefficient planes + selection plane over R1
@@ -437,16 +444,32 @@ struct Fused {
     int b, x0, y0;
   };
 
-  // ---- phase 0: projection matrices into LDS ---------------------------------
-  static VSL_DEV void phase0(const KParams& kp, const Block& bk, int tid, float* lds) {
+  // ---- phase 0: projection matrices (layers.py:189) and inv_K into wave-uniform registers -----------
+  static VSL_DEV void phase0(const KParams& kp, const Block& bk, int tid, ThreadState<S>& st) {
     if (tid == 0 && bk.b == 0 && bk.x0 == 0 && bk.y0 == 0 && kp.counter) *kp.counter = 0u;
-    if (tid < 12 * S) {
-      int s = tid / 12, e = tid % 12;
-      lds[OFF_MAT + tid] = proj_entry(kp.K + 16 * bk.b, kp.T[s] + 16 * bk.b, e / 4, e % 4);
-    } else if (tid < 12 * S + 9) {
-      int e = tid - 12 * S;
-      lds[OFF_MAT + tid] = kp.invK[16 * bk.b + (e / 3) * 4 + (e % 3)];
+#if defined(__HIPCC__)
+    const int lane = tid & 63;
+    float v = 0.0f;
+    if (lane < 12 * S) {
+      const int s = lane / 12, e = lane % 12;
+      v = proj_entry(kp.K + 16 * bk.b, kp.T[s] + 16 * bk.b, e / 4, e % 4);
+    } else if (lane < 12 * S + 9) {
+      const int e = lane - 12 * S;
+      v = kp.invK[16 * bk.b + (e / 3) * 4 + (e % 3)];
     }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int e = 0; e < 12; ++e)
+        st.m.P[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s * 12 + e));
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+      st.m.ik[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 12 * S + e));
+#else
+    for (int s = 0; s < S; ++s)
+      for (int e = 0; e < 12; ++e) st.m.P[s][e] = proj_entry(kp.K + 16 * bk.b, kp.T[s] + 16 * bk.b, e / 4, e % 4);
+    for (int e = 0; e < 9; ++e) st.m.ik[e] = kp.invK[16 * bk.b + (e / 3) * 4 + (e % 3)];
+#endif
   }
 
   // ---- phase 1: two horizontally adjacent R2 positions per thread -------------------
@@ -462,7 +485,7 @@ struct Fused {
     const float* dispb = kp.disp + (size_t)bk.b * HW;
     const float* tgtb = kp.tgt + (size_t)bk.b * 3 * HW;
     const int py = reflect_clamp(bk.y0 - 2 + ry, H);
-    const float* ik = lds + OFF_MAT + 12 * S;
+    const float* ik = st.m.ik;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
     const float fy = (float)py;
     // rays share the y part: inv_K[i][1]*y is added after inv_K[i][0]*x in the reference's order
@@ -490,7 +513,7 @@ struct Fused {
       }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        const float* P = lds + OFF_MAT + 12 * s;
+        const float* P = st.m.P[s];
         float cam[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -693,7 +716,7 @@ struct Fused {
           fxm[k][2] += (float)(jx0 + k == W - 2);
         }
       }
-      const float* ikm = lds + OFF_MAT + 12 * S;
+      const float* ikm = st.m.ik;
       const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
 
       float gD[2] = {0.0f, 0.0f};
@@ -819,7 +842,7 @@ struct Fused {
           gix[k] *= lx;
           giy[k] *= ly;
         }
-        const float* P = lds + OFF_MAT + 12 * s;
+        const float* P = st.m.P[s];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           if (!ok[k]) {

@@ -134,8 +134,7 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   }
 #endif
   VSL_STAMP(0);
-  F::phase0(kp, bk, tid, lds);
-  __syncthreads();
+  F::phase0(kp, bk, tid, st);
   VSL_STAMP(1);
   F::phase1(kp, bk, tid, lds, st);
   VSL_STAMP(2);

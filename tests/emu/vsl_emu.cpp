@@ -46,7 +46,7 @@ void run_tiles(KParams kp) {
         const int lin = (b * ty + by) * tx + bx;
         // poison LDS so that reads of unwritten cells show up as NaNs in the results
         for (auto& v : lds) v = NAN;
-        for (int t = 0; t < kNT; ++t) F::phase0(kp, bk, t, lds.data());
+        for (int t = 0; t < kNT; ++t) F::phase0(kp, bk, t, st[t]);
         for (int t = 0; t < kNT; ++t) F::phase1(kp, bk, t, lds.data(), st[t]);
         for (int t = 0; t < kNT; ++t) F::phase2(kp, bk, t, lds.data(), st[t]);
         for (int t = 0; t < kNT; ++t) F::phase3(kp, bk, t, lds.data(), st[t]);
