@@ -206,9 +206,12 @@ def main():
     if world != max(args.gpus, 1) and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d; launch N>1 with torch.distributed.run" % (args.gpus, world),
               file=sys.stderr)
-    dev = torch.device("cuda", local)
+    # rehearsal on a one-GPU box: VSL_BENCH_DEVICE pins every rank to one card and VSL_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device); a real run uses neither
+    dev = torch.device("cuda", int(os.environ.get("VSL_BENCH_DEVICE", local)))
     torch.cuda.set_device(dev)
-    D.init("nccl", dev)
+    backend = os.environ.get("VSL_BENCH_BACKEND", "nccl")
+    D.init(backend, dev)
 
     B, H, W = args.batch, args.height, args.width
     fids = [0, -1, 1, "s"] if args.stereo else [0, -1, 1]
