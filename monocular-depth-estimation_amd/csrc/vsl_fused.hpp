@@ -105,6 +105,21 @@ struct KParams {
 #endif
 };
 
+// The per-head part of the arguments as the fused tile program sees it (several disparity heads share one
+// KParams; the kernel picks the head of its tile).
+struct HeadView {
+  const float* disp;
+  float* gphoto;
+  float* gedge;
+  float* ident_sel;
+  float* partials;
+  unsigned int* counter;
+  float cst_ssim, cst_l1;
+};
+VSL_DEV HeadView head_view(const KParams& kp) {
+  return HeadView{kp.disp, kp.gphoto, kp.gedge, kp.ident_sel, kp.partials, kp.counter, kp.cst_ssim, kp.cst_l1};
+}
+
 // ----------------------------------------------------------------------------
 // small helpers
 // ----------------------------------------------------------------------------
@@ -143,6 +158,23 @@ VSL_DEV float proj_entry(const float* K, const float* T, int i, int j) {
   float acc = VSL_FMUL(K[i * 4 + 0], T[0 * 4 + j]);
   for (int q = 1; q < 4; ++q) acc = VSL_FADD(acc, VSL_FMUL(K[i * 4 + q], T[q * 4 + j]));
   return acc;
+}
+
+// kp.src[s] / kp.T[s] through compile-time indices only: a run-time index into the by-value argument struct
+// (a source loop the compiler did not unroll) would move the whole struct into scratch memory
+VSL_DEV const float* src_image(const KParams& kp, int s) {
+  const float* p = kp.src[0];
+  if (s == 1) p = kp.src[1];
+  if (s == 2) p = kp.src[2];
+  if (s == 3) p = kp.src[3];
+  return p;
+}
+VSL_DEV const float* src_pose(const KParams& kp, int s) {
+  const float* p = kp.T[0];
+  if (s == 1) p = kp.T[1];
+  if (s == 2) p = kp.T[2];
+  if (s == 3) p = kp.T[3];
+  return p;
 }
 
 struct alignas(8) float2v {
@@ -343,7 +375,7 @@ struct Ident {
       for (int c = 0; c < 3; ++c) {
         lds[c * PN + p] = (tgtb + (size_t)c * HW)[pix];
 #pragma unroll
-        for (int s = 0; s < S; ++s) lds[(3 + s * 3 + c) * PN + p] = (kp.src[s] + ((size_t)bk.b * 3 + c) * HW)[pix];
+        for (int s = 0; s < S; ++s) lds[(3 + s * 3 + c) * PN + p] = (src_image(kp, s) + ((size_t)bk.b * 3 + c) * HW)[pix];
       }
     }
   }
@@ -445,14 +477,20 @@ struct Fused {
   };
 
   // ---- phase 0: projection matrices (layers.py:189) and inv_K into wave-uniform registers -----------
-  static VSL_DEV void phase0(const KParams& kp, const Block& bk, int tid, ThreadState<S>& st) {
-    if (tid == 0 && bk.b == 0 && bk.x0 == 0 && bk.y0 == 0 && kp.counter) *kp.counter = 0u;
+  static VSL_DEV void phase0(const KParams& kp, const HeadView& hv, const Block& bk, int tid, ThreadState<S>& st) {
+    if (tid == 0 && bk.b == 0 && bk.x0 == 0 && bk.y0 == 0 && hv.counter) *hv.counter = 0u;
 #if defined(__HIPCC__)
     const int lane = tid & 63;
     float v = 0.0f;
     if (lane < 12 * S) {
-      const int s = lane / 12, e = lane % 12;
-      v = proj_entry(kp.K + 16 * bk.b, kp.T[s] + 16 * bk.b, e / 4, e % 4);
+      // the pose pointer is picked with compile-time indices: indexing the by-value argument struct with a
+      // per-lane value would move the whole struct into scratch memory
+      const float* Tp = kp.T[0];
+#pragma unroll
+      for (int s = 1; s < S; ++s)
+        if (lane >= 12 * s) Tp = src_pose(kp, s);
+      const int e = lane % 12;
+      v = proj_entry(kp.K + 16 * bk.b, Tp + 16 * bk.b, e / 4, e % 4);
     } else if (lane < 12 * S + 9) {
       const int e = lane - 12 * S;
       v = kp.invK[16 * bk.b + (e / 3) * 4 + (e % 3)];
@@ -467,7 +505,7 @@ struct Fused {
       st.m.ik[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 12 * S + e));
 #else
     for (int s = 0; s < S; ++s)
-      for (int e = 0; e < 12; ++e) st.m.P[s][e] = proj_entry(kp.K + 16 * bk.b, kp.T[s] + 16 * bk.b, e / 4, e % 4);
+      for (int e = 0; e < 12; ++e) st.m.P[s][e] = proj_entry(kp.K + 16 * bk.b, src_pose(kp, s) + 16 * bk.b, e / 4, e % 4);
     for (int e = 0; e < 9; ++e) st.m.ik[e] = kp.invK[16 * bk.b + (e / 3) * 4 + (e % 3)];
 #endif
   }
@@ -475,14 +513,14 @@ struct Fused {
   // ---- phase 1: two horizontally adjacent R2 positions per thread -------------------
   // Every thread warps exactly one pair of R2 and keeps where its taps were; the threads whose
   // pair is interior use that again in phase 3.
-  static VSL_DEV void phase1(const KParams& kp, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
+  static VSL_DEV void phase1(const KParams& kp, const HeadView& hv, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
     st.photo = 0.0f;
     const int ry = tid / ROWP, rx0 = 2 * (tid % ROWP);
     if (ry >= R2H || rx0 >= R2W) return;
     const int H = kp.H, W = kp.W;
     const unsigned HW = (unsigned)H * (unsigned)W;
     // per-image bases are uniform over the workgroup; per-lane offsets stay unsigned 32-bit
-    const float* dispb = kp.disp + (size_t)bk.b * HW;
+    const float* dispb = hv.disp + (size_t)bk.b * HW;
     const float* tgtb = kp.tgt + (size_t)bk.b * 3 * HW;
     const int py = reflect_clamp(bk.y0 - 2 + ry, H);
     const float* ik = st.m.ik;
@@ -529,7 +567,7 @@ struct Fused {
         const float gx = VSL_FMUL(VSL_FSUB(VSL_FDIV(u, wm1), 0.5f), 2.0f);
         const float gy = VSL_FMUL(VSL_FSUB(VSL_FDIV(v, hm1), 0.5f), 2.0f);
         const Taps tx = axis_taps(gx, W), ty = axis_taps(gy, H);
-        const float* sp = kp.src[s] + (size_t)bk.b * 3 * HW;
+        const float* sp = src_image(kp, s) + (size_t)bk.b * 3 * HW;
         // both x taps of a row come from one 8-byte load at min(x0, W-2)
         const bool xs = tx.i1 != tx.i0, ys = ty.i1 != ty.i0;
         const unsigned o0 = (unsigned)ty.i0 * (unsigned)W + (unsigned)(xs ? tx.i0 : W - 2);
@@ -560,7 +598,7 @@ struct Fused {
   }
 
   // ---- phase 2: photometric error on R1, running argmin, coefficients -----------
-  static VSL_DEV void phase2(const KParams& kp, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
+  static VSL_DEV void phase2(const KParams& kp, const HeadView& hv, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
     const int qy = tid / ROWP, qx0 = 2 * (tid % ROWP);
     if (qy >= R1H || qx0 >= R1W) return;
     const int gy = bk.y0 - 1 + qy, gx0 = bk.x0 - 1 + qx0;
@@ -653,14 +691,14 @@ struct Fused {
       sel[q1 + k] = win[k];
       if (interior[k]) {
         st.photo += best[k];
-        if (kp.automask && kp.ident_sel)
-          kp.ident_sel[((size_t)bk.b * kp.H + gy) * kp.W + gx0 + k] = (win[k] >= 0.0f) ? 1.0f : 0.0f;
+        if (kp.automask && hv.ident_sel)
+          hv.ident_sel[((size_t)bk.b * kp.H + gy) * kp.W + gx0 + k] = (win[k] >= 0.0f) ? 1.0f : 0.0f;
       }
     }
   }
 
   // ---- phase 3: gradients of the interior pair ---------------------------------
-  static VSL_DEV void phase3(const KParams& kp, const Block& bk, int tid, const float* lds, ThreadState<S>& st) {
+  static VSL_DEV void phase3(const KParams& kp, const HeadView& hv, const Block& bk, int tid, const float* lds, ThreadState<S>& st) {
 #pragma unroll
     for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
     st.part[0] = st.photo;
@@ -669,7 +707,7 @@ struct Fused {
     // over the last two interior rows, so that the R2 rows from TH on -- the whole last wave -- stay idle
     const int row = tid / ROWP, ip = tid % ROWP - 1;
     if (row >= TH) {
-      phase3_smooth(kp, bk, tid, lds, st);
+      phase3_smooth(kp, hv, bk, tid, lds, st);
       return;
     }
     if (ip < 0 || ip >= TW / 2) return;
@@ -791,7 +829,7 @@ struct Fused {
           for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int k = 0; k < 2; ++k)
-              g[s][k][c] = kp.cst_ssim * gs[s][k] - kp.cst_l1 * mf[AVG ? 0 : s][1][1 + k] * sgn(yv[k] - xv[s][k]);
+              g[s][k][c] = hv.cst_ssim * gs[s][k] - hv.cst_l1 * mf[AVG ? 0 : s][1][1 + k] * sgn(yv[k] - xv[s][k]);
           VSL_SCHED_FENCE();
         }
       }
@@ -817,7 +855,7 @@ struct Fused {
           const unsigned o1 = o0 + (((pk >> 29) & 1u) ? (unsigned)W : 0u);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const float* pc = kp.src[s] + ((size_t)bk.b * 3 + c) * HW;
+            const float* pc = src_image(kp, s) + ((size_t)bk.b * 3 + c) * HW;
             const TexelPair a = load_texel_pair(pc + o0), b = load_texel_pair(pc + o1);
             tv[k][c][0] = xs ? a.lo : a.hi;
             tv[k][c][1] = a.hi;
@@ -885,14 +923,14 @@ struct Fused {
     if (kp.want_grad) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
-        if (ok[k]) kp.gphoto[(size_t)bk.b * HW + (size_t)jy * W + jx0 + k] = g_disp[k];
+        if (ok[k]) hv.gphoto[(size_t)bk.b * HW + (size_t)jy * W + jx0 + k] = g_disp[k];
     }
   }
 
   // Edge-aware smoothness of the tile, layers.py:211-226 with the 1/(mean+1e-7) factor applied later.  It needs
   // only the disparity and target planes, so the wave that has no interior pixels in phase 3 (R2 rows from TH on)
   // computes it for the whole tile while the other waves do the photometric gradient.
-  static VSL_DEV void phase3_smooth(const KParams& kp, const Block& bk, int tid, const float* lds, ThreadState<S>& st) {
+  static VSL_DEV void phase3_smooth(const KParams& kp, const HeadView& hv, const Block& bk, int tid, const float* lds, ThreadState<S>& st) {
     const int H = kp.H, W = kp.W;
     const size_t HW = (size_t)H * W;
     constexpr int NSM = NT - TH * ROWP;  // threads of the idle rows
@@ -934,7 +972,7 @@ struct Fused {
           if (t == 2) st.part[3] = fmaf(w, fabsf(diff), st.part[3]);
         }
         st.part[1] += d0;
-        if (kp.want_grad) kp.gedge[(size_t)bk.b * HW + (size_t)jy * W + jx] = e;
+        if (kp.want_grad) hv.gedge[(size_t)bk.b * HW + (size_t)jy * W + jx] = e;
       }
     }
   }
@@ -960,13 +998,13 @@ struct Fused {
     }
   }
   // after another barrier: thread k < NPART adds the RED_SPLIT pieces of row k
-  static VSL_DEV void phase4_sum_b(const KParams& kp, int block_linear, int tid, const float* lds) {
+  static VSL_DEV void phase4_sum_b(const HeadView& hv, int block_linear, int tid, const float* lds) {
     if (tid >= NPART) return;
     const float* r = lds + RED_FLOATS + tid * RED_SPLIT;
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < RED_SPLIT; ++i) s += r[i];
-    kp.partials[(size_t)block_linear * kPartStride + tid] = s;
+    hv.partials[(size_t)block_linear * kPartStride + tid] = s;
   }
 };
 

@@ -111,15 +111,10 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   int head = 0;
   const int block_linear = swizzled_tile<TH>(kp_in, ha.n_heads, head, bk.b, bk.x0, bk.y0);
   if (block_linear < 0) return;
-  KParams kp = kp_in;  // uniform: the head's pointers and constants replace the placeholders
-  kp.disp = ha.disp[head];
-  kp.gphoto = ha.gphoto[head];
-  kp.gedge = ha.gedge[head];
-  kp.ident_sel = ha.ident_sel[head];
-  kp.partials = ha.partials[head];
-  kp.counter = ha.counter[head];
-  kp.cst_ssim = ha.cst_ssim[head];
-  kp.cst_l1 = ha.cst_l1[head];
+  const KParams& kp = kp_in;
+  // the head's pointers and constants (a patched copy of the argument struct would end up in scratch memory)
+  const HeadView hv{ha.disp[head],     ha.gphoto[head],  ha.gedge[head],    ha.ident_sel[head],
+                    ha.partials[head], ha.counter[head], ha.cst_ssim[head], ha.cst_l1[head]};
 
   ThreadState<S> st;
 #ifdef VSL_STAMPS
@@ -134,17 +129,17 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   }
 #endif
   VSL_STAMP(0);
-  F::phase0(kp, bk, tid, st);
+  F::phase0(kp, hv, bk, tid, st);
   VSL_STAMP(1);
-  F::phase1(kp, bk, tid, lds, st);
+  F::phase1(kp, hv, bk, tid, lds, st);
   VSL_STAMP(2);
   __syncthreads();
   VSL_STAMP(3);
-  F::phase2(kp, bk, tid, lds, st);
+  F::phase2(kp, hv, bk, tid, lds, st);
   VSL_STAMP(4);
   __syncthreads();
   VSL_STAMP(5);
-  F::phase3(kp, bk, tid, lds, st);
+  F::phase3(kp, hv, bk, tid, lds, st);
   VSL_STAMP(6);
   __syncthreads();
   VSL_STAMP(7);
@@ -152,7 +147,7 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   __syncthreads();
   F::phase4_sum_a(tid, lds);
   __syncthreads();
-  F::phase4_sum_b(kp, block_linear, tid, lds);
+  F::phase4_sum_b(hv, block_linear, tid, lds);
   VSL_STAMP(8);
 #ifdef VSL_STAMPS
   if ((threadIdx.x & 63) == 0)

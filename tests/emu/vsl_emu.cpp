@@ -39,6 +39,7 @@ void run_tiles(KParams kp) {
   const int tx = (kp.W + kTW - 1) / kTW, ty = (kp.H + kTH - 1) / kTH;
   std::vector<float> lds(F::LDS_FLOATS);
   std::vector<ThreadState<S>> st(kNT);
+  const HeadView hv = head_view(kp);
   for (int b = 0; b < kp.B; ++b)
     for (int by = 0; by < ty; ++by)
       for (int bx = 0; bx < tx; ++bx) {
@@ -46,13 +47,13 @@ void run_tiles(KParams kp) {
         const int lin = (b * ty + by) * tx + bx;
         // poison LDS so that reads of unwritten cells show up as NaNs in the results
         for (auto& v : lds) v = NAN;
-        for (int t = 0; t < kNT; ++t) F::phase0(kp, bk, t, st[t]);
-        for (int t = 0; t < kNT; ++t) F::phase1(kp, bk, t, lds.data(), st[t]);
-        for (int t = 0; t < kNT; ++t) F::phase2(kp, bk, t, lds.data(), st[t]);
-        for (int t = 0; t < kNT; ++t) F::phase3(kp, bk, t, lds.data(), st[t]);
+        for (int t = 0; t < kNT; ++t) F::phase0(kp, hv, bk, t, st[t]);
+        for (int t = 0; t < kNT; ++t) F::phase1(kp, hv, bk, t, lds.data(), st[t]);
+        for (int t = 0; t < kNT; ++t) F::phase2(kp, hv, bk, t, lds.data(), st[t]);
+        for (int t = 0; t < kNT; ++t) F::phase3(kp, hv, bk, t, lds.data(), st[t]);
         for (int t = 0; t < kNT; ++t) F::phase4_store(t, lds.data(), st[t]);
         for (int t = 0; t < kNT; ++t) F::phase4_sum_a(t, lds.data());
-        for (int t = 0; t < kNT; ++t) F::phase4_sum_b(kp, lin, t, lds.data());
+        for (int t = 0; t < kNT; ++t) F::phase4_sum_b(hv, lin, t, lds.data());
       }
 }
 }  // namespace

@@ -8,8 +8,8 @@ import numpy as np, torch
 import bench
 import mde_amd._abi as abi
 
-B, H, W = 12, 192, 640
-fids = [0, -1, 1]
+B, H, W = [int(v) for v in os.environ.get('VSL_STAMP_SHAPE', '12,192,640').split(',')]
+fids = [0, -1, 1, 's'] if os.environ.get('VSL_STAMP_STEREO') else [0, -1, 1]
 dev = torch.device("cuda:0")
 data, t = bench.build_inputs(B, H, W, fids, 1, dev)
 step = bench.LossStep(t, B, H, W, fids, 1, dev)
