@@ -37,7 +37,11 @@
 #define VSL_EXP(x) __expf(x)
 // keeps the instruction scheduler from interleaving the unrolled per-channel / per-source bodies
 // (interleaving them multiplies the number of live registers)
+#ifdef VSL_NO_FENCE
+#define VSL_SCHED_FENCE()
+#else
 #define VSL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #else
 // host build: compile with -ffp-contract=off so that a*b+c is never fused
 #define VSL_DEV inline

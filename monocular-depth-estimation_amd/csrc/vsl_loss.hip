@@ -384,12 +384,15 @@ int launch_fused(const KParams& kp, const HeadArgs& ha, dim3 grid, hipStream_t s
   using F = Fused<kTW, TH, NT, S, AVG>;
   constexpr size_t lds_bytes = (size_t)F::LDS_FLOATS * sizeof(float);
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit the 160 KiB LDS of a CU");
-  static thread_local bool configured = false;
-  if (!configured) {
+  // the attribute belongs to the (function, device) pair: remember it per device of the calling thread
+  static thread_local unsigned long long configured = 0;  // bit d = done on device d (devices >= 64: every call)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(VSL_ERR_LAUNCH_FAILED, "hipGetDevice failed");
+  if (dev >= 64 || !((configured >> dev) & 1ull)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vsl_fused_kernel<S, AVG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(VSL_ERR_LAUNCH_FAILED, "hipFuncSetAttribute(max dynamic LDS) failed");
-    configured = true;
+    if (dev < 64) configured |= 1ull << dev;
   }
   size_t launch_lds = lds_bytes;
 #ifdef VSL_STAMPS
