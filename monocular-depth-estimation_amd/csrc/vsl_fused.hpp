@@ -464,7 +464,8 @@ struct Fused {
   static constexpr int OFF_DSP = OFF_WRP + S * 3 * P2;  // 1 plane over R2
   static constexpr int OFF_COEF = OFF_DSP + P2;         // NSET*9 coefficient planes + selection plane over R1
   static constexpr int COEF_FLOATS = (NSET * 9 + 1) * P1;
-  static constexpr int RED_PITCH = NT + 1;
+  // row pitch = 8 mod 64: the (row, piece) items of a wave in phase4_sum_a then read 64 different banks
+  static constexpr int RED_PITCH = ((NT + 63) / 64) * 64 + 8;
   static constexpr int RED_FLOATS = NPART * RED_PITCH;
   static constexpr int RED_SPLIT = 8;
   // Tap records of the last two interior rows, handed from the threads that warped them (R2 rows TH, TH+1) to
