@@ -44,3 +44,39 @@ def test_argument_validation_without_gpu():
     assert abi.lib.vsl_loss_forward(ctypes.byref(d), None, 0, None, None, None) == -1   # NULL tensors
     with pytest.raises(abi.VslError):
         abi.check(-1)
+
+
+def test_head_validation_without_gpu():
+    """vsl_loss_forward_heads / _backward_heads reject malformed head tables before anything is launched."""
+    import mde_amd._abi as abi
+    d = abi.LossDesc()
+    d.B, d.H, d.W, d.S = 2, 16, 32, 1
+    d.min_depth, d.max_depth, d.inv_num_scales = 0.1, 100.0, 1.0
+    fake = 0x1000                                   # never dereferenced: validation fails first
+    d.target = d.K = d.inv_K = fake
+    d.source[0] = d.T[0] = fake
+    need = abi.lib.vsl_loss_workspace_bytes(ctypes.byref(d))
+    heads = (abi.Head * 2)()
+
+    def fill(h, ws=fake * 16, nbytes=need, n_scales=1):
+        h.disp, h.losses, h.workspace, h.workspace_bytes, h.n_scales = fake, fake, ws, nbytes, n_scales
+        h.scale_weight[0] = 1e-3
+
+    for h in heads:
+        fill(h)
+    err = lambda: abi.lib.vsl_last_error_string()
+    assert abi.lib.vsl_loss_forward_heads(ctypes.byref(d), heads, 0, None) == -1 and b"heads" in err()
+    assert abi.lib.vsl_loss_forward_heads(ctypes.byref(d), heads, abi.MAX_HEADS + 1, None) == -1
+    fill(heads[1], nbytes=need - 1)
+    assert abi.lib.vsl_loss_forward_heads(ctypes.byref(d), heads, 2, None) == -2 and b"workspace" in err()
+    fill(heads[1], ws=fake * 16 + 8)
+    assert abi.lib.vsl_loss_forward_heads(ctypes.byref(d), heads, 2, None) == -1 and b"aligned" in err()
+    fill(heads[1], n_scales=9)
+    assert abi.lib.vsl_loss_forward_heads(ctypes.byref(d), heads, 2, None) == -1 and b"n_scales" in err()
+    fill(heads[1])
+    heads[1].disp = None
+    assert abi.lib.vsl_loss_forward_heads(ctypes.byref(d), heads, 2, None) == -1
+    d.flags = abi.FLAG_NO_GRAD
+    fill(heads[1])
+    assert abi.lib.vsl_loss_backward_heads(ctypes.byref(d), heads, 2, None) == -1 and b"NO_GRAD" in err()
+    assert abi.lib.vsl_loss_forward_heads(None, heads, 2, None) == -1
