@@ -186,6 +186,10 @@ int vsl_debug_fused_occupancy(int S, int avg_reprojection);
  * the first head's workspace) and shared.  Results are bit-identical to one
  * vsl_loss_forward / vsl_loss_backward call per head.
  */
+/* vsl_head.flags: this head is evaluated forward only (a teacher head next to a student head,
+ * Python/Trainer_distilation.py:845-870); vsl_loss_backward_heads skips it */
+#define VSL_HEAD_NO_GRAD 1u
+
 typedef struct vsl_head {
   const float* disp;          /* [B,1,H,W] this head's sigmoid disparity                          */
   void* workspace;            /* vsl_loss_workspace_bytes(desc) bytes, 256-byte aligned, per head   */
@@ -194,6 +198,7 @@ typedef struct vsl_head {
   float* identity_selection;  /* out [B,H,W] or NULL (forward)                                     */
   int32_t n_scales;                    /* loss slots of this head, 1..VSL_MAX_SCALES               */
   float scale_weight[VSL_MAX_SCALES];  /* disparity_smoothness / 2**scale (Trainer.py:614)         */
+  uint32_t flags;                      /* VSL_HEAD_*                                                */
   const float* grad_losses;   /* in [VSL_LOSS_SLOTS] or NULL = d/d losses[VSL_LOSS_TOTAL] (backward) */
   float* grad_disp;           /* out [B,1,H,W] or NULL (backward)                                  */
   float* grad_T[VSL_MAX_SOURCES]; /* out [B,4,4] each or NULL (backward)                           */

@@ -16,6 +16,7 @@ MAX_SOURCES = 4
 MAX_SCALES = 8
 MAX_HEADS = 8
 FLAG_AUTOMASK, FLAG_AVG_REPROJECTION, FLAG_NO_SSIM, FLAG_NO_GRAD = 1, 2, 4, 8
+HEAD_NO_GRAD = 1
 LOSS_TOTAL, LOSS_PHOTO, LOSS_SMOOTH, LOSS_SCALE0 = 0, 1, 2, 3
 LOSS_SLOTS = 3 + MAX_SCALES
 
@@ -48,7 +49,7 @@ class Head(ctypes.Structure):
     _fields_ = [
         ("disp", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("losses", ctypes.c_void_p), ("identity_selection", ctypes.c_void_p),
-        ("n_scales", ctypes.c_int32), ("scale_weight", ctypes.c_float * MAX_SCALES),
+        ("n_scales", ctypes.c_int32), ("scale_weight", ctypes.c_float * MAX_SCALES), ("flags", ctypes.c_uint32),
         ("grad_losses", ctypes.c_void_p), ("grad_disp", ctypes.c_void_p), ("grad_T", ctypes.c_void_p * MAX_SOURCES),
     ]
 

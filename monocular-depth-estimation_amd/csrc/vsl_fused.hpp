@@ -119,9 +119,10 @@ struct HeadView {
   float* partials;
   unsigned int* counter;
   float cst_ssim, cst_l1;
+  int want_grad;  // 0: forward only (no coefficients, no gradient planes)
 };
 VSL_DEV HeadView head_view(const KParams& kp) {
-  return HeadView{kp.disp, kp.gphoto, kp.gedge, kp.ident_sel, kp.partials, kp.counter, kp.cst_ssim, kp.cst_l1};
+  return HeadView{kp.disp, kp.gphoto, kp.gedge, kp.ident_sel, kp.partials, kp.counter, kp.cst_ssim, kp.cst_l1, kp.want_grad};
 }
 
 // ----------------------------------------------------------------------------
@@ -658,7 +659,7 @@ struct Fused {
         SsimOut o[2];
         o[0].f = o[1].f = 0.0f;
         o[0].A = o[0].B = o[0].G = o[1].A = o[1].B = o[1].G = 0.0f;
-        if (!kp.no_ssim) ssim_pair(xw, yw, sy[c], syy[c], kp.want_grad != 0, o);
+        if (!kp.no_ssim) ssim_pair(xw, yw, sy[c], syy[c], hv.want_grad != 0, o);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           fsum[k] += o[k].f;
@@ -743,7 +744,7 @@ struct Fused {
     const size_t HW = (size_t)H * W;
 
     float g_disp[2] = {0.0f, 0.0f};
-    if (kp.want_grad) {
+    if (hv.want_grad) {
       // Reflection-padding fold (backward of layers.py:240,249-250): a window centred on the image
       // border counts twice for the pixel next to the border.  Only tiles that contain column 1 /
       // W-2 or row 1 / H-2 need the weights; the test is uniform over the workgroup.
@@ -925,7 +926,7 @@ struct Fused {
         }
     }
 
-    if (kp.want_grad) {
+    if (hv.want_grad) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
         if (ok[k]) hv.gphoto[(size_t)bk.b * HW + (size_t)jy * W + jx0 + k] = g_disp[k];
@@ -977,7 +978,7 @@ struct Fused {
           if (t == 2) st.part[3] = fmaf(w, fabsf(diff), st.part[3]);
         }
         st.part[1] += d0;
-        if (kp.want_grad) hv.gedge[(size_t)bk.b * HW + (size_t)jy * W + jx] = e;
+        if (hv.want_grad) hv.gedge[(size_t)bk.b * HW + (size_t)jy * W + jx] = e;
       }
     }
   }

@@ -98,6 +98,7 @@ struct HeadArgs {
   float* partials[VSL_MAX_HEADS];
   unsigned int* counter[VSL_MAX_HEADS];
   float cst_ssim[VSL_MAX_HEADS], cst_l1[VSL_MAX_HEADS];
+  int want_grad[VSL_MAX_HEADS];
 };
 
 template <int S, bool AVG>
@@ -114,7 +115,8 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   const KParams& kp = kp_in;
   // the head's pointers and constants (a patched copy of the argument struct would end up in scratch memory)
   const HeadView hv{ha.disp[head],     ha.gphoto[head],  ha.gedge[head],    ha.ident_sel[head],
-                    ha.partials[head], ha.counter[head], ha.cst_ssim[head], ha.cst_l1[head]};
+                    ha.partials[head], ha.counter[head], ha.cst_ssim[head], ha.cst_l1[head],
+                    ha.want_grad[head]};
 
   ThreadState<S> st;
 #ifdef VSL_STAMPS
@@ -553,6 +555,7 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
     ha.counter[h] = (unsigned int*)(ws + L.off_counter);
     ha.cst_ssim[h] = no_ssim ? 0.0f : (float)(base * d->ssim_weight / 27.0);
     ha.cst_l1[h] = no_ssim ? (float)(base / 3.0) : (float)(base * d->l1_weight / 3.0);
+    ha.want_grad[h] = want_grad && !(hd.flags & VSL_HEAD_NO_GRAD);
     FinalizeHead& fh = fp.head[h];
     fh.n_scales = hd.n_scales;
     for (int i = 0; i < VSL_MAX_SCALES; ++i) fh.scale_weight[i] = i < hd.n_scales ? hd.scale_weight[i] : 0.0f;
@@ -616,6 +619,11 @@ int backward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, vo
     const vsl_head& hd = heads[h];
     const char* ws = (const char*)hd.workspace;
     GradHead& gh = gp.head[h];
+    if (hd.flags & VSL_HEAD_NO_GRAD) {  // forward-only head: nothing was prepared, nothing is written
+      if (hd.grad_disp || hd.grad_T[0] || hd.grad_T[1] || hd.grad_T[2] || hd.grad_T[3])
+        return fail(VSL_ERR_INVALID_ARGUMENT, "gradient requested from a VSL_HEAD_NO_GRAD head");
+      continue;
+    }
     gh.gphoto = (const float*)(ws + L.off_gphoto);
     gh.gedge = (const float*)(ws + L.off_gedge);
     gh.c12 = (const float*)(ws + L.off_c12);

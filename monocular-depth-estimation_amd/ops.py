@@ -164,6 +164,7 @@ class _FusedHeadsFn(torch.autograd.Function):
             hd.disp, hd.workspace, hd.workspace_bytes = disps[h].data_ptr(), ws[h].data_ptr(), nbytes
             hd.losses = losses[h].data_ptr()
             hd.identity_selection = ident[h].data_ptr() if automask else None
+            hd.flags = _abi.HEAD_NO_GRAD if cfg["forward_only"][h] else 0
             sw = cfg["scale_weights"][h]
             hd.n_scales = len(sw)
             for i, w in enumerate(sw):
@@ -181,7 +182,8 @@ class _FusedHeadsFn(torch.autograd.Function):
         dev = ctx.ws[0].device
         need = ctx.needs_input_grad  # (cfg, n_heads, disps..., poses...)
         g_losses = g_losses.contiguous().float()
-        grad_disp = [torch.empty(B, 1, H, W, dtype=torch.float32, device=dev) if need[2 + h] else None
+        live = [not (ctx.heads[h].flags & _abi.HEAD_NO_GRAD) for h in range(n_heads)]
+        grad_disp = [torch.empty(B, 1, H, W, dtype=torch.float32, device=dev) if (need[2 + h] and live[h]) else None
                      for h in range(n_heads)]
         want_T = [need[2 + n_heads + s] for s in range(S)]
         grad_T = torch.empty(n_heads, S, B, 4, 4, dtype=torch.float32, device=dev) if any(want_T) else None
@@ -190,11 +192,12 @@ class _FusedHeadsFn(torch.autograd.Function):
             hd.grad_losses = g_losses[h].data_ptr()
             hd.grad_disp = grad_disp[h].data_ptr() if grad_disp[h] is not None else None
             for s in range(S):
-                hd.grad_T[s] = grad_T[h, s].data_ptr() if want_T[s] else None
+                hd.grad_T[s] = grad_T[h, s].data_ptr() if (want_T[s] and live[h]) else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(_abi.lib.vsl_loss_backward_heads(ctypes.byref(ctx.desc), ctx.heads, n_heads, stream))
-        # every head differentiates the same pose matrices: their gradients add up
-        gT = [grad_T[:, s].sum(0) if want_T[s] else None for s in range(S)]
+        # every head with gradients differentiates the same pose matrices: their gradients add up
+        idx = [h for h in range(n_heads) if live[h]]
+        gT = [grad_T[idx, s].sum(0) if (want_T[s] and idx) else None for s in range(S)]
         return (None, None) + tuple(grad_disp) + tuple(gT)
 
 
@@ -204,11 +207,13 @@ def fused_view_synthesis_loss_heads(disps: Sequence[torch.Tensor], target: torch
                                     avg_reprojection: bool = False, no_ssim: bool = False,
                                     scale_weights: Optional[Sequence[Sequence[float]]] = None,
                                     inv_num_scales: float = 1.0, warp_scale: float = 1.0, min_depth: float = 0.1,
-                                    max_depth: float = 100.0, seed: int = 0):
+                                    max_depth: float = 100.0, seed: int = 0,
+                                    forward_only: Optional[Sequence[bool]] = None):
     """``fused_view_synthesis_loss`` for several disparity tensors over the same images and poses in one
     launch.  ``scale_weights[h]`` are head h's smoothness weights (default: [1e-3 / 2**h]).  Returns
     ``(losses [n_heads, LOSS_SLOTS], identity_selection [n_heads, B, H, W] or None)``; the result of every
-    head is bit-identical to a separate ``fused_view_synthesis_loss`` call."""
+    head is bit-identical to a separate ``fused_view_synthesis_loss`` call.  ``forward_only[h]`` marks a head
+    that gets no gradient (a teacher head next to the student's): its gradient work is skipped."""
     n_heads = len(disps)
     if not 1 <= n_heads <= _abi.MAX_HEADS:
         raise ValueError("need 1..%d heads" % _abi.MAX_HEADS)
@@ -229,15 +234,19 @@ def fused_view_synthesis_loss_heads(disps: Sequence[torch.Tensor], target: torch
     n_id = 1 if avg_reprojection else S
     if noise is not None and automask and tuple(noise.shape) != (B, n_id, H, W):
         raise ValueError("noise must be [B,%d,H,W]" % n_id)
+    forward_only = [False] * n_heads if forward_only is None else [bool(f) for f in forward_only]
+    if len(forward_only) != n_heads:
+        raise ValueError("forward_only needs one entry per head")
     flags = (_abi.FLAG_AUTOMASK if automask else 0) | (_abi.FLAG_AVG_REPROJECTION if avg_reprojection else 0) \
         | (_abi.FLAG_NO_SSIM if no_ssim else 0)
     poses = [_f32c(p, "pose") for p in poses]
-    disps = [_f32c(d, "disp") for d in disps]
+    disps = [_f32c(d.detach() if forward_only[h] else d, "disp") for h, d in enumerate(disps)]
     want_grad = torch.is_grad_enabled() and any(t.requires_grad for t in disps + poses)
     cfg = dict(flags=flags, want_grad=want_grad, min_depth=float(min_depth), max_depth=float(max_depth),
                warp_scale=float(warp_scale), scale_weights=[[float(w) for w in ws] for ws in scale_weights],
                inv_num_scales=float(inv_num_scales), target=_f32c(target, "target"),
                sources=[_f32c(s, "source") for s in sources], K=_f32c(K, "K"), inv_K=_f32c(inv_K, "inv_K"),
-               noise=_f32c(noise, "noise") if (noise is not None and automask) else None, seed=int(seed))
+               noise=_f32c(noise, "noise") if (noise is not None and automask) else None, seed=int(seed),
+               forward_only=forward_only)
     losses, ident = _FusedHeadsFn.apply(cfg, n_heads, *disps, *poses)
     return losses, (ident if automask else None)

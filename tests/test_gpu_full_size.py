@@ -224,3 +224,36 @@ def test_merged_heads_equal_separate_calls(shape, fids):
     for s in range(len(poses)):
         err = float((poses[s].grad - gT_sum[s]).norm() / gT_sum[s].norm())
         assert err < 1e-6, err
+
+
+def test_student_and_forward_only_teacher_in_one_launch():
+    """Distillation layout through the merged call: head 0 (student) with gradients, head 1 (teacher) marked
+    forward only.  Both match their separate evaluations bit for bit; gradients come from the student alone."""
+    import mde_amd.synth as synth
+    from mde_amd.ops import fused_view_synthesis_loss, fused_view_synthesis_loss_heads
+    B, H, W, fids = 4, 192, 640, [0, -1, 1]
+    data = synth.make_batch(B, H, W, fids, seed=13, n_heads=2)
+    img = lambda f: data[("image", f)].to(DEV)
+    noise = data["noise"].to(DEV)
+    common = dict(scale_weights=[[1e-3], [1e-3]], warp_scale=0.9)
+
+    disps = [data[("disp", h)].to(DEV).requires_grad_(True) for h in range(2)]
+    poses = [data[("cam_T_cam", f)].to(DEV).requires_grad_(True) for f in fids[1:]]
+    losses, ident = fused_view_synthesis_loss_heads(disps, img(0), [img(f) for f in fids[1:]], data["K"].to(DEV),
+                                                    data["inv_K"].to(DEV), poses, noise, forward_only=[False, True], **common)
+    losses[0, 0].backward()
+    assert disps[1].grad is None
+
+    d0 = data[("disp", 0)].to(DEV).requires_grad_(True)
+    p0 = [data[("cam_T_cam", f)].to(DEV).requires_grad_(True) for f in fids[1:]]
+    l0, i0 = fused_view_synthesis_loss(d0, img(0), [img(f) for f in fids[1:]], data["K"].to(DEV), data["inv_K"].to(DEV),
+                                       p0, noise, scale_weights=[1e-3], warp_scale=0.9)
+    l0[0].backward()
+    assert torch.equal(l0, losses[0]) and torch.equal(i0, ident[0]) and torch.equal(d0.grad, disps[0].grad)
+    for a, b in zip(p0, poses):
+        assert torch.equal(a.grad, b.grad)
+    with torch.no_grad():
+        l1, i1 = fused_view_synthesis_loss(data[("disp", 1)].to(DEV), img(0), [img(f) for f in fids[1:]], data["K"].to(DEV),
+                                           data["inv_K"].to(DEV), [p.detach() for p in poses], noise, scale_weights=[1e-3],
+                                           warp_scale=0.9)
+    assert torch.equal(l1, losses[1]) and torch.equal(i1, ident[1])
