@@ -445,10 +445,13 @@ struct Ident {
 // ----------------------------------------------------------------------------
 // fused tile program
 // ----------------------------------------------------------------------------
-template <int TW, int TH, int NT, int S, bool AVG>
+// HALO = 2: the full program (loss and everything for the backward).  HALO = 1: forward only -- phases 0 and 1
+// on the tile grown by 1, then phase_forward instead of phases 2 and 3 (no coefficients, no gradients).
+template <int TW, int TH, int NT, int S, bool AVG, int HALO = 2>
 struct Fused {
   static_assert(TW % 2 == 0, "tile width must be even");
-  static constexpr int R2W = TW + 4, R2H = TH + 4, P2 = R2W * R2H;
+  static_assert(HALO == 1 || HALO == 2, "halo is 1 (forward only) or 2");
+  static constexpr int R2W = TW + 2 * HALO, R2H = TH + 2 * HALO, P2 = R2W * R2H;
   static constexpr int R1W = TW + 2, R1H = TH + 2, P1 = R1W * R1H;
   // Threads map to pixel pairs as (row = tid / ROWP, pair = tid % ROWP) in every phase.  ROWP = 16
   // makes each 16-lane LDS access group lie inside one tile row, which keeps the 8-byte window
@@ -464,18 +467,19 @@ struct Fused {
   static constexpr int OFF_WRP = OFF_TGT + 3 * P2;      // S*3 planes over R2
   static constexpr int OFF_DSP = OFF_WRP + S * 3 * P2;  // 1 plane over R2
   static constexpr int OFF_COEF = OFF_DSP + P2;         // NSET*9 coefficient planes + selection plane over R1
-  static constexpr int COEF_FLOATS = (NSET * 9 + 1) * P1;
+  static constexpr int COEF_FLOATS = HALO == 2 ? (NSET * 9 + 1) * P1 : 0;
   // row pitch = 8 mod 64: the (row, piece) items of a wave in phase4_sum_a then read 64 different banks
   static constexpr int RED_PITCH = ((NT + 63) / 64) * 64 + 8;
-  static constexpr int RED_FLOATS = NPART * RED_PITCH;
+  static constexpr int NRED = HALO == 2 ? NPART : 4;  // partial sums that can be non-zero
+  static constexpr int RED_FLOATS = NRED * RED_PITCH;
   static constexpr int RED_SPLIT = 8;
   // Tap records of the last two interior rows, handed from the threads that warped them (R2 rows TH, TH+1) to
   // the threads of R2 rows 0, 1: phase 3 then keeps the last wave (R2 rows TH..TH+3) completely idle instead of
   // running four half-empty waves.
   static constexpr int OFF_XFER = OFF_COEF + COEF_FLOATS;
-  static constexpr int XFER_FLOATS = 2 * ROWP * 2 * S * 3;
+  static constexpr int XFER_FLOATS = HALO == 2 ? 2 * ROWP * 2 * S * 3 : 0;
   static constexpr int LDS_MAIN = OFF_XFER + XFER_FLOATS;
-  static constexpr int RED_TOTAL = RED_FLOATS + NPART * RED_SPLIT;
+  static constexpr int RED_TOTAL = RED_FLOATS + NRED * RED_SPLIT;
   static constexpr int LDS_FLOATS = LDS_MAIN > RED_TOTAL ? LDS_MAIN : RED_TOTAL;
 
   struct Block {
@@ -528,14 +532,14 @@ struct Fused {
     // per-image bases are uniform over the workgroup; per-lane offsets stay unsigned 32-bit
     const float* dispb = hv.disp + (size_t)bk.b * HW;
     const float* tgtb = kp.tgt + (size_t)bk.b * 3 * HW;
-    const int py = reflect_clamp(bk.y0 - 2 + ry, H);
+    const int py = reflect_clamp(bk.y0 - HALO + ry, H);
     const float* ik = st.m.ik;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
     const float fy = (float)py;
     // rays share the y part: inv_K[i][1]*y is added after inv_K[i][0]*x in the reference's order
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int px = reflect_clamp(bk.x0 - 2 + rx0 + k, W);
+      const int px = reflect_clamp(bk.x0 - HALO + rx0 + k, W);
       const int p2 = ry * R2W + rx0 + k;
       const unsigned pix = (unsigned)py * (unsigned)W + (unsigned)px;
       const float d = dispb[pix];
@@ -593,7 +597,7 @@ struct Fused {
         ch.ty = ty.t;
         ch.packed = (int)(o0 | ((unsigned)xs << 28) | ((unsigned)ys << 29) | ((unsigned)(tx.live != 0.0f) << 30) |
                           ((unsigned)(ty.live != 0.0f) << 31));
-        if (ry >= TH && ry < TH + 2) {
+        if (HALO == 2 && ry >= TH && ry < TH + 2) {
           float* xf = lds + OFF_XFER + (((ry - TH) * ROWP + tid % ROWP) * 2 + k) * (S * 3) + s * 3;
           xf[0] = ch.tx;
           xf[1] = ch.ty;
@@ -937,60 +941,142 @@ struct Fused {
   // only the disparity and target planes, so the wave that has no interior pixels in phase 3 (R2 rows from TH on)
   // computes it for the whole tile while the other waves do the photometric gradient.
   static VSL_DEV void phase3_smooth(const KParams& kp, const HeadView& hv, const Block& bk, int tid, const float* lds, ThreadState<S>& st) {
+    constexpr int NSM = NT - TH * ROWP;  // threads of the idle rows
+    for (int q = tid - TH * ROWP; q < TH * (TW / 2); q += NSM) smooth_pair(kp, hv, bk, lds, st, q / (TW / 2), q % (TW / 2));
+  }
+
+  // smoothness terms of the interior pixel pair (iy, ip): sums into st.part[1..3], edge gradient to hv.gedge
+  static VSL_DEV void smooth_pair(const KParams& kp, const HeadView& hv, const Block& bk, const float* lds, ThreadState<S>& st,
+                                  int iy, int ip) {
     const int H = kp.H, W = kp.W;
     const size_t HW = (size_t)H * W;
-    constexpr int NSM = NT - TH * ROWP;  // threads of the idle rows
-    for (int q = tid - TH * ROWP; q < TH * (TW / 2); q += NSM) {
-      const int iy = q / (TW / 2), ip = q % (TW / 2);
-      const int jy = bk.y0 + iy, jx0 = bk.x0 + 2 * ip;
-      if (jy >= H || jx0 >= W) continue;
-      const int p2 = (2 + iy) * R2W + 2 + 2 * ip;
+    const int jy = bk.y0 + iy, jx0 = bk.x0 + 2 * ip;
+    if (jy >= H || jx0 >= W) return;
+    const int p2 = (HALO + iy) * R2W + HALO + 2 * ip;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int jx = jx0 + k;
-        if (jx >= W) continue;
-        const int pp = p2 + k;
-        const float d0 = lds[OFF_DSP + pp];
-        float ax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum_c |I - I_neighbour| for right, left, down, up
+    for (int k = 0; k < 2; ++k) {
+      const int jx = jx0 + k;
+      if (jx >= W) continue;
+      const int pp = p2 + k;
+      const float d0 = lds[OFF_DSP + pp];
+      float ax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum_c |I - I_neighbour| for right, left, down, up
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float* tp = lds + OFF_TGT + c * P2;
-          const float i0 = tp[pp];
-          ax[0] += fabsf(i0 - tp[pp + 1]);
-          ax[1] += fabsf(tp[pp - 1] - i0);
-          ax[2] += fabsf(i0 - tp[pp + R2W]);
-          ax[3] += fabsf(tp[pp - R2W] - i0);
-        }
-        const float dn[4] = {lds[OFF_DSP + pp + 1], lds[OFF_DSP + pp - 1], lds[OFF_DSP + pp + R2W],
-                             lds[OFF_DSP + pp - R2W]};
-        const bool has[4] = {jx + 1 < W, jx > 0, jy + 1 < H, jy > 0};
-        float e = 0.0f;
+      for (int c = 0; c < 3; ++c) {
+        const float* tp = lds + OFF_TGT + c * P2;
+        const float i0 = tp[pp];
+        ax[0] += fabsf(i0 - tp[pp + 1]);
+        ax[1] += fabsf(tp[pp - 1] - i0);
+        ax[2] += fabsf(i0 - tp[pp + R2W]);
+        ax[3] += fabsf(tp[pp - R2W] - i0);
+      }
+      const float dn[4] = {lds[OFF_DSP + pp + 1], lds[OFF_DSP + pp - 1], lds[OFF_DSP + pp + R2W],
+                           lds[OFF_DSP + pp - R2W]};
+      const bool has[4] = {jx + 1 < W, jx > 0, jy + 1 < H, jy > 0};
+      float e = 0.0f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (!has[t]) continue;
-          const float w = VSL_EXP(-ax[t] * (1.0f / 3.0f));
-          const float inv_n = (t < 2) ? kp.inv_nx : kp.inv_ny;
-          // right/down edges are owned by this pixel (first operand), left/up by the neighbour
-          const float diff = (t == 0 || t == 2) ? d0 - dn[t] : dn[t] - d0;
-          const float sg = sgn(diff) * w * inv_n;
-          e += (t == 0 || t == 2) ? sg : -sg;
-          if (t == 0) st.part[2] = fmaf(w, fabsf(diff), st.part[2]);
-          if (t == 2) st.part[3] = fmaf(w, fabsf(diff), st.part[3]);
-        }
-        st.part[1] += d0;
-        if (hv.want_grad) hv.gedge[(size_t)bk.b * HW + (size_t)jy * W + jx] = e;
+      for (int t = 0; t < 4; ++t) {
+        if (!has[t]) continue;
+        const float w = VSL_EXP(-ax[t] * (1.0f / 3.0f));
+        const float inv_n = (t < 2) ? kp.inv_nx : kp.inv_ny;
+        // right/down edges are owned by this pixel (first operand), left/up by the neighbour
+        const float diff = (t == 0 || t == 2) ? d0 - dn[t] : dn[t] - d0;
+        const float sg = sgn(diff) * w * inv_n;
+        e += (t == 0 || t == 2) ? sg : -sg;
+        if (t == 0) st.part[2] = fmaf(w, fabsf(diff), st.part[2]);
+        if (t == 2) st.part[3] = fmaf(w, fabsf(diff), st.part[3]);
+      }
+      st.part[1] += d0;
+      if (hv.want_grad) hv.gedge[(size_t)bk.b * HW + (size_t)jy * W + jx] = e;
+    }
+  }
+
+  // ---- forward only (HALO = 1): photometric error, selection and smoothness of the interior pair ----
+  // Same arithmetic per pixel as phase 2 (Trainer.py:481-495,551-605), without coefficients; replaces phases 2, 3.
+  static VSL_DEV void phase_forward(const KParams& kp, const HeadView& hv, const Block& bk, int tid, const float* lds,
+                                    ThreadState<S>& st) {
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
+    const int iy = tid / ROWP, ip = tid % ROWP;
+    if (iy >= TH || ip >= TW / 2) return;
+    const int jy = bk.y0 + iy, jx0 = bk.x0 + 2 * ip;
+    if (jy >= kp.H || jx0 >= kp.W) return;
+    const bool ok[2] = {true, jx0 + 1 < kp.W};
+    const int base = iy * R2W + 2 * ip;  // top-left of the pair's windows in the planes over the tile grown by 1
+    const size_t HW = (size_t)kp.H * kp.W;
+    const size_t pix0 = (size_t)bk.b * HW + (size_t)jy * kp.W + jx0;
+    float best[2] = {INFINITY, INFINITY};
+    if (kp.automask) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (ok[k]) best[k] = kp.idmin[pix0 + k];
+    }
+    bool warped_wins[2] = {false, false};
+    float rsum[2] = {0.0f, 0.0f};
+    float sy[3][2], syy[3][2];
+    if (!kp.no_ssim) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float yw[3][4];
+        load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
+        y_stats(yw, sy[c], syy[c]);
+        VSL_SCHED_FENCE();
       }
     }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      float fsum[2] = {0.0f, 0.0f}, lsum[2] = {0.0f, 0.0f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float yw[3][4], xw[3][4];
+        load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
+        load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
+        lsum[0] += fabsf(yw[1][1] - xw[1][1]);
+        lsum[1] += fabsf(yw[1][2] - xw[1][2]);
+        if (!kp.no_ssim) {
+          SsimOut o[2];
+          ssim_pair(xw, yw, sy[c], syy[c], false, o);
+          fsum[0] += o[0].f;
+          fsum[1] += o[1].f;
+        }
+        VSL_SCHED_FENCE();
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float e = kp.no_ssim ? lsum[k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[k], kp.l1_w3 * lsum[k]);
+        e *= kp.warp_scale;
+        if (AVG) {
+          rsum[k] += e;
+        } else if (ok[k] && e < best[k]) {
+          best[k] = e;
+          warped_wins[k] = true;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (AVG) {
+        const float e = rsum[k] * (1.0f / S);
+        if (ok[k] && e < best[k]) {
+          best[k] = e;
+          warped_wins[k] = true;
+        }
+      }
+      if (ok[k]) {
+        st.part[0] += best[k];
+        if (kp.automask && hv.ident_sel) hv.ident_sel[pix0 + k] = warped_wins[k] ? 1.0f : 0.0f;
+      }
+    }
+    smooth_pair(kp, hv, bk, lds, st, iy, ip);
   }
 
   // ---- phase 4: deterministic block reduction ----------------------------------
   static VSL_DEV void phase4_store(int tid, float* lds, const ThreadState<S>& st) {
 #pragma unroll
-    for (int k = 0; k < NPART; ++k) lds[k * RED_PITCH + tid] = st.part[k];
+    for (int k = 0; k < NRED; ++k) lds[k * RED_PITCH + tid] = st.part[k];
   }
   // after a barrier: item (row, part) sums every RED_SPLIT-th element of a row in a fixed order
   static VSL_DEV void phase4_sum_a(int tid, float* lds) {
-    for (int item = tid; item < NPART * RED_SPLIT; item += NT) {
+    for (int item = tid; item < NRED * RED_SPLIT; item += NT) {
       const int row = item / RED_SPLIT, part = item % RED_SPLIT;
       const float* r = lds + row * RED_PITCH;
       float s0 = 0.0f, s1 = 0.0f;
@@ -1003,13 +1089,16 @@ struct Fused {
       lds[RED_FLOATS + item] = s0 + s1;
     }
   }
-  // after another barrier: thread k < NPART adds the RED_SPLIT pieces of row k
+  // after another barrier: thread k < NPART adds the RED_SPLIT pieces of row k (rows that cannot be
+  // non-zero in the forward-only program are written as zeros: the finalize kernel reads all of them)
   static VSL_DEV void phase4_sum_b(const HeadView& hv, int block_linear, int tid, const float* lds) {
     if (tid >= NPART) return;
-    const float* r = lds + RED_FLOATS + tid * RED_SPLIT;
     float s = 0.0f;
+    if (tid < NRED) {
+      const float* r = lds + RED_FLOATS + tid * RED_SPLIT;
 #pragma unroll
-    for (int i = 0; i < RED_SPLIT; ++i) s += r[i];
+      for (int i = 0; i < RED_SPLIT; ++i) s += r[i];
+    }
     hv.partials[(size_t)block_linear * kPartStride + tid] = s;
   }
 };

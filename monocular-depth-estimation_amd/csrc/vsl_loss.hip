@@ -158,6 +158,36 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
 }
 
 // --------------------------------------------------------------------------
+// forward-only tile kernel (every head of the launch without gradients: validation, teacher heads)
+// --------------------------------------------------------------------------
+template <int S, bool AVG>
+__global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG))) void vsl_forward_kernel(const KParams kp_in, const HeadArgs ha) {
+  constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
+  using F = Fused<kTW, TH, NT, S, AVG, 1>;
+  __shared__ __align__(16) float lds[F::LDS_FLOATS];
+  const int tid = threadIdx.x;
+  typename F::Block bk;
+  int head = 0;
+  const int block_linear = swizzled_tile<TH>(kp_in, ha.n_heads, head, bk.b, bk.x0, bk.y0);
+  if (block_linear < 0) return;
+  const KParams& kp = kp_in;
+  const HeadView hv{ha.disp[head],     ha.gphoto[head],  ha.gedge[head],    ha.ident_sel[head],
+                    ha.partials[head], ha.counter[head], ha.cst_ssim[head], ha.cst_l1[head],
+                    0};
+  ThreadState<S> st;
+  F::phase0(kp, hv, bk, tid, st);
+  F::phase1(kp, hv, bk, tid, lds, st);
+  __syncthreads();
+  F::phase_forward(kp, hv, bk, tid, lds, st);
+  __syncthreads();
+  F::phase4_store(tid, lds, st);
+  __syncthreads();
+  F::phase4_sum_a(tid, lds);
+  __syncthreads();
+  F::phase4_sum_b(hv, block_linear, tid, lds);
+}
+
+// --------------------------------------------------------------------------
 // identity minimum
 // --------------------------------------------------------------------------
 template <int S, bool AVG>
@@ -425,6 +455,15 @@ int launch_fused(const KParams& kp, const HeadArgs& ha, dim3 grid, hipStream_t s
 }
 
 template <int S>
+void launch_forward_s(const KParams& kp, const HeadArgs& ha, bool avg, dim3 grid, hipStream_t stream) {
+  constexpr int NTF = tile_threads(fused_tile_h(S, false)), NTA = tile_threads(fused_tile_h(S, true));
+  if (avg)
+    hipLaunchKernelGGL((vsl_forward_kernel<S, true>), grid, dim3(NTA), 0, stream, kp, ha);
+  else
+    hipLaunchKernelGGL((vsl_forward_kernel<S, false>), grid, dim3(NTF), 0, stream, kp, ha);
+}
+
+template <int S>
 int launch_fused_s(const KParams& kp, const HeadArgs& ha, bool avg, dim3 grid, hipStream_t stream) {
   return avg ? launch_fused<S, true>(kp, ha, grid, stream) : launch_fused<S, false>(kp, ha, grid, stream);
 }
@@ -591,11 +630,22 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
   }
   int rc = VSL_OK;
   if (ev0) (void)hipEventRecord(ev0, stream);
-  switch (d->S) {
-    case 1: rc = launch_fused_s<1>(kp, ha, avg, grid, stream); break;
-    case 2: rc = launch_fused_s<2>(kp, ha, avg, grid, stream); break;
-    case 3: rc = launch_fused_s<3>(kp, ha, avg, grid, stream); break;
-    default: rc = launch_fused_s<4>(kp, ha, avg, grid, stream); break;
+  bool any_grad = false;
+  for (int h = 0; h < n_heads; ++h) any_grad = any_grad || ha.want_grad[h] != 0;
+  if (any_grad) {
+    switch (d->S) {
+      case 1: rc = launch_fused_s<1>(kp, ha, avg, grid, stream); break;
+      case 2: rc = launch_fused_s<2>(kp, ha, avg, grid, stream); break;
+      case 3: rc = launch_fused_s<3>(kp, ha, avg, grid, stream); break;
+      default: rc = launch_fused_s<4>(kp, ha, avg, grid, stream); break;
+    }
+  } else {  // no head wants gradients: the forward-only tile program (halo 1, no coefficient planes)
+    switch (d->S) {
+      case 1: launch_forward_s<1>(kp, ha, avg, grid, stream); break;
+      case 2: launch_forward_s<2>(kp, ha, avg, grid, stream); break;
+      case 3: launch_forward_s<3>(kp, ha, avg, grid, stream); break;
+      default: launch_forward_s<4>(kp, ha, avg, grid, stream); break;
+    }
   }
   if (ev1) (void)hipEventRecord(ev1, stream);
   if (rc) return rc;

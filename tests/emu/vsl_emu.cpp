@@ -35,18 +35,30 @@ template <int S, bool AVG>
 void run_tiles(KParams kp) {
   constexpr int kTH = fused_tile_h(S, AVG), kNT = tile_threads(kTH);
   using F = Fused<kTW, kTH, kNT, S, AVG>;
+  using F1 = Fused<kTW, kTH, kNT, S, AVG, 1>;   // forward-only program
   if (kp.automask) run_ident<S, AVG>(kp);
+  const bool fwd_only = kp.want_grad == 0;
   const int tx = (kp.W + kTW - 1) / kTW, ty = (kp.H + kTH - 1) / kTH;
-  std::vector<float> lds(F::LDS_FLOATS);
+  std::vector<float> lds(F::LDS_FLOATS > F1::LDS_FLOATS ? F::LDS_FLOATS : F1::LDS_FLOATS);
   std::vector<ThreadState<S>> st(kNT);
   const HeadView hv = head_view(kp);
   for (int b = 0; b < kp.B; ++b)
     for (int by = 0; by < ty; ++by)
       for (int bx = 0; bx < tx; ++bx) {
         typename F::Block bk{b, bx * kTW, by * kTH};
+        typename F1::Block bk1{b, bx * kTW, by * kTH};
         const int lin = (b * ty + by) * tx + bx;
         // poison LDS so that reads of unwritten cells show up as NaNs in the results
         for (auto& v : lds) v = NAN;
+        if (fwd_only) {
+          for (int t = 0; t < kNT; ++t) F1::phase0(kp, hv, bk1, t, st[t]);
+          for (int t = 0; t < kNT; ++t) F1::phase1(kp, hv, bk1, t, lds.data(), st[t]);
+          for (int t = 0; t < kNT; ++t) F1::phase_forward(kp, hv, bk1, t, lds.data(), st[t]);
+          for (int t = 0; t < kNT; ++t) F1::phase4_store(t, lds.data(), st[t]);
+          for (int t = 0; t < kNT; ++t) F1::phase4_sum_a(t, lds.data());
+          for (int t = 0; t < kNT; ++t) F1::phase4_sum_b(hv, lin, t, lds.data());
+          continue;
+        }
         for (int t = 0; t < kNT; ++t) F::phase0(kp, hv, bk, t, st[t]);
         for (int t = 0; t < kNT; ++t) F::phase1(kp, hv, bk, t, lds.data(), st[t]);
         for (int t = 0; t < kNT; ++t) F::phase2(kp, hv, bk, t, lds.data(), st[t]);

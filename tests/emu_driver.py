@@ -48,7 +48,7 @@ def _ptr(a):
 
 def run_emu(disp, target, sources, K, inv_K, Ts, noise, automask=True, avg=False, no_ssim=False,
             warp_scale=1.0, scale_weights=(1e-3,), inv_num_scales=1.0, min_depth=0.1, max_depth=100.0,
-            so_path=None, seed=0):
+            so_path=None, seed=0, want_grad=True):
     """All arrays float32 numpy.  Returns dict(loss, photo, smooth, loss_scales, grad_disp, grad_T, ident_sel)."""
     lib = ctypes.CDLL(so_path or build_emu())
     assert lib.vsl_emu_kparams_size() == ctypes.sizeof(KParams), "KParams mirror out of date"
@@ -93,7 +93,7 @@ def run_emu(disp, target, sources, K, inv_K, Ts, noise, automask=True, avg=False
     kp.gphoto, kp.gedge, kp.ident_sel, kp.partials = _ptr(gphoto), _ptr(gedge), _ptr(ident), _ptr(partials)
     kp.counter = None
     kp.idmin = _ptr(idmin)
-    kp.want_grad = 1
+    kp.want_grad = 1 if want_grad else 0
     rc = lib.vsl_emu_tiles(ctypes.byref(kp), int(avg))
     assert rc == 0
 

@@ -45,3 +45,19 @@ def test_in_kernel_noise_generator_breaks_ties_like_explicit_noise():
     c = E.run_emu(*args, None, seed=7)
     assert abs(a["loss"] - b["loss"]) < 1e-4 * a["loss"]
     assert b["loss"] == c["loss"] and np.array_equal(b["grad_disp"], c["grad_disp"])
+
+
+@pytest.mark.parametrize("name", ["b2_24x80_automask", "b1_13x37_noautomask_avg", "b2_24x80_stereo", "b2_24x80_automask_nossim",
+                                  "b2_48x160_automask", "b3_16x33_sharp"])
+def test_forward_only_program_matches_reference_fixture(name):
+    """The forward-only tile program (halo 1, no coefficient planes): loss, smoothness and selection."""
+    cfg, z = load_case(name)
+    srcs = [fid_key(f) for f in cfg["frame_ids"]][1:]
+    r = E.run_emu(z["disp"], z["image_0"], [z["image_%s" % f] for f in srcs], z["K"], z["inv_K"],
+                  [z["T_%s" % f] for f in srcs], z["noise"] if cfg["automask"] else None,
+                  automask=cfg["automask"], avg=cfg["avg_reprojection"], no_ssim=cfg["no_ssim"],
+                  scale_weights=[1e-3 / 2 ** s for s in cfg["scales"]], want_grad=False)
+    assert abs(r["loss"] - float(z["loss"])) <= TOL * float(z["loss"])
+    assert abs(r["smooth"] - float(z["smooth"])) <= TOL * float(z["smooth"])
+    if cfg["automask"]:
+        assert np.array_equal(r["ident_sel"], z["identity_selection"])

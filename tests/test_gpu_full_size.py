@@ -166,7 +166,9 @@ def test_two_heads_share_identity_minimum_and_forward_only_head():
     assert np.array_equal(l_sh, l_again) and np.array_equal(g_sh, g_again)          # deterministic
     l_t_full, s_t_full, _ = run(1, abi.FLAG_AUTOMASK, shared=True)
     l_t_fwd, s_t_fwd, _ = run(1, abi.FLAG_AUTOMASK | abi.FLAG_NO_GRAD, shared=True)
-    assert np.array_equal(l_t_full, l_t_fwd) and np.array_equal(s_t_full, s_t_fwd)
+    # the forward-only program sums the same per-pixel values in another order: equal to float32 summation noise
+    np.testing.assert_allclose(l_t_fwd, l_t_full, rtol=2e-6, atol=0)
+    assert np.array_equal(s_t_full, s_t_fwd)
     assert not np.array_equal(l_t_full, l_sh)                                        # the heads do differ
 
     with pytest.raises(abi.VslError):
