@@ -258,4 +258,5 @@ def test_student_and_forward_only_teacher_in_one_launch():
         l1, i1 = fused_view_synthesis_loss(data[("disp", 1)].to(DEV), img(0), [img(f) for f in fids[1:]], data["K"].to(DEV),
                                            data["inv_K"].to(DEV), [p.detach() for p in poses], noise, scale_weights=[1e-3],
                                            warp_scale=0.9)
-    assert torch.equal(l1, losses[1]) and torch.equal(i1, ident[1])
+    # (a launch without any gradient runs the forward-only program: same per-pixel values, other summation order)
+    assert torch.allclose(l1, losses[1], rtol=2e-6, atol=0) and torch.equal(i1, ident[1])
