@@ -609,6 +609,14 @@ struct Fused {
 
   // ---- phase 2: photometric error on R1, running argmin, coefficients -----------
   static VSL_DEV void phase2(const KParams& kp, const HeadView& hv, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
+    // no_ssim is uniform over the launch: two specialised bodies instead of a test inside every channel loop
+    if (kp.no_ssim)
+      phase2_t<true>(kp, hv, bk, tid, lds, st);
+    else
+      phase2_t<false>(kp, hv, bk, tid, lds, st);
+  }
+  template <bool NOSSIM>
+  static VSL_DEV void phase2_t(const KParams& kp, const HeadView& hv, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
     const int qy = tid / ROWP, qx0 = 2 * (tid % ROWP);
     if (qy >= R1H || qx0 >= R1W) return;
     const int gy = bk.y0 - 1 + qy, gx0 = bk.x0 - 1 + qx0;
@@ -640,7 +648,7 @@ struct Fused {
     }
     // target-side window sums once per channel
     float sy[3][2], syy[3][2];
-    if (!kp.no_ssim) {
+    if (!NOSSIM) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float yw[3][4];
@@ -660,22 +668,25 @@ struct Fused {
         load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
         lsum[0] += fabsf(yw[1][1] - xw[1][1]);
         lsum[1] += fabsf(yw[1][2] - xw[1][2]);
-        SsimOut o[2];
-        o[0].f = o[1].f = 0.0f;
-        o[0].A = o[0].B = o[0].G = o[1].A = o[1].B = o[1].G = 0.0f;
-        if (!kp.no_ssim) ssim_pair(xw, yw, sy[c], syy[c], hv.want_grad != 0, o);
+        if (!NOSSIM) {
+          SsimOut o[2];
+          ssim_pair(xw, yw, sy[c], syy[c], hv.want_grad != 0, o);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          fsum[k] += o[k].f;
-          cf[k][c * 3 + 0] = o[k].A;
-          cf[k][c * 3 + 1] = o[k].B;
-          cf[k][c * 3 + 2] = o[k].G;
+          for (int k = 0; k < 2; ++k) {
+            fsum[k] += o[k].f;
+            cf[k][c * 3 + 0] = o[k].A;
+            cf[k][c * 3 + 1] = o[k].B;
+            cf[k][c * 3 + 2] = o[k].G;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) cf[k][c * 3 + 0] = cf[k][c * 3 + 1] = cf[k][c * 3 + 2] = 0.0f;
         }
         VSL_SCHED_FENCE();
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        float e = kp.no_ssim ? lsum[k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[k], kp.l1_w3 * lsum[k]);
+        float e = NOSSIM ? lsum[k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[k], kp.l1_w3 * lsum[k]);
         e *= kp.warp_scale;
         if (AVG) {
           rsum[k] += e;
