@@ -166,6 +166,22 @@ def cpu_baseline(data, B, H, W, fids, seconds=12.0):
             "kind": "port", "sample": "%d passes of a batch-%d slice of the workload, 1 head, float64 images" % (n, nb)}
 
 
+def copy_ceiling(dev, nbytes=1 << 29, reps=20):
+    """Measured device-to-device copy rate (read + write bytes per second, GB/s): what a pure streaming kernel
+    reaches on this card, reported next to the 8 TB/s specification peak."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def pmc_traffic(workload_key):
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, in KB; FETCH_SIZE doubled as gfx950 tallies 128-byte read
@@ -294,7 +310,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(key),
                          "kernel": "vsl_fused_kernel", "kernel_ms": fused_ms, "heads_per_launch": n_launch_heads,
                          "algorithmic_bytes": alg_bytes, "forward_call_ms": fwd_ms, "backward_call_ms": bwd_ms,
-                         "frac_whole_call": alg_bytes / (head_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "frac_whole_call": alg_bytes / (head_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "copy_ceiling_GBs": copy_ceiling(dev)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(data, B, H, W, fids)
