@@ -213,6 +213,40 @@ int vsl_loss_backward_heads(const vsl_loss_desc* desc, const vsl_head* heads, in
 int vsl_debug_time_fused(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, int reps, float* avg_ms,
                          void* stream);
 
+/*
+ * Pose preparation in front of the loss: transformation_from_parameters (Python/layers.py:28-45, with
+ * rot_from_axisangle :64-103 and get_translation_matrix :48-61) for every source frame of a batch in one
+ * launch, as Trainer.predict_pose calls it (Python/Trainer.py:393 inverted for negative frame ids in
+ * "pairs" mode, :414 otherwise).  axisangle[s] / translation[s] point at the first of B rows of 3 floats,
+ * `aa_stride` / `tr_stride` floats apart (the slices axisangle[:, i] of a [B,F,1,3] network output have
+ * stride 3*F).  t_scale, if not NULL, is a [B] factor on the translation: the mean inverse depth of the
+ * "posecnn" pose model (Python/Trainer.py:446-455).
+ */
+typedef struct vsl_pose_desc {
+  int32_t B, n_src;                            /* images, source frames (1..VSL_MAX_SOURCES)          */
+  int32_t aa_stride, tr_stride;                /* floats between consecutive images, >= 3             */
+  uint32_t invert_mask;                        /* bit s set: source s uses invert=True                 */
+  uint32_t reserved;
+  const float* axisangle[VSL_MAX_SOURCES];     /* [B,3] strided                                       */
+  const float* translation[VSL_MAX_SOURCES];   /* [B,3] strided                                       */
+  const float* t_scale;                        /* [B] or NULL                                         */
+} vsl_pose_desc;
+
+/* T[s]: out [B,4,4] contiguous. */
+int vsl_pose_fwd(const vsl_pose_desc* desc, float* const* T, void* stream);
+/* g_T[s]: in [B,4,4]; g_axisangle[s], g_translation[s]: out [B,3] contiguous (tables or entries may be
+ * NULL); g_t_scale: out [B] summed over the sources, or NULL. */
+int vsl_pose_bwd(const vsl_pose_desc* desc, const float* const* g_T, float* const* g_axisangle,
+                 float* const* g_translation, float* g_t_scale, void* stream);
+
+/* Per-image mean of 1/depth with depth = disp_to_depth(disp)[1] (Python/Trainer.py:451-452):
+ * disp [B,1,H,W] -> out [B].  Backward: g_disp [B,1,H,W] = (or +=, if accumulate) g_out[b] * d out[b] / d disp. */
+size_t vsl_mean_inv_depth_workspace_bytes(int B);
+int vsl_mean_inv_depth_fwd(const float* disp, float* out, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                           float min_depth, float max_depth, void* stream);
+int vsl_mean_inv_depth_bwd(const float* disp, const float* g_out, float* g_disp, int accumulate, int B, int H, int W,
+                           float min_depth, float max_depth, void* stream);
+
 /* Library version, e.g. 100 for 0.1.0. */
 int vsl_version(void);
 

@@ -26,6 +26,8 @@ EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", 
            "vsl_project_fwd", "vsl_project_bwd_workspace_bytes", "vsl_project_bwd",
            "vsl_grid_sample_fwd", "vsl_grid_sample_bwd", "vsl_ssim_fwd", "vsl_ssim_bwd",
            "vsl_smooth_workspace_bytes", "vsl_smooth_fwd", "vsl_smooth_bwd",
+           "vsl_pose_fwd", "vsl_pose_bwd",
+           "vsl_mean_inv_depth_workspace_bytes", "vsl_mean_inv_depth_fwd", "vsl_mean_inv_depth_bwd",
            "vsl_debug_fused_occupancy", "vsl_debug_time_fused", "vsl_last_error_string", "vsl_version")
 
 
@@ -51,6 +53,16 @@ class Head(ctypes.Structure):
         ("losses", ctypes.c_void_p), ("identity_selection", ctypes.c_void_p),
         ("n_scales", ctypes.c_int32), ("scale_weight", ctypes.c_float * MAX_SCALES), ("flags", ctypes.c_uint32),
         ("grad_losses", ctypes.c_void_p), ("grad_disp", ctypes.c_void_p), ("grad_T", ctypes.c_void_p * MAX_SOURCES),
+    ]
+
+
+class PoseDesc(ctypes.Structure):
+    """Mirror of ``vsl_pose_desc`` (include/vsloss.h)."""
+    _fields_ = [
+        ("B", ctypes.c_int32), ("n_src", ctypes.c_int32), ("aa_stride", ctypes.c_int32), ("tr_stride", ctypes.c_int32),
+        ("invert_mask", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+        ("axisangle", ctypes.c_void_p * MAX_SOURCES), ("translation", ctypes.c_void_p * MAX_SOURCES),
+        ("t_scale", ctypes.c_void_p),
     ]
 
 
@@ -106,6 +118,17 @@ def _load():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_size_t
         fn.argtypes = [I, I, I]
+    PT = ctypes.POINTER(ctypes.c_void_p)
+    lib.vsl_pose_fwd.restype = ctypes.c_int
+    lib.vsl_pose_fwd.argtypes = [ctypes.POINTER(PoseDesc), PT, P]
+    lib.vsl_pose_bwd.restype = ctypes.c_int
+    lib.vsl_pose_bwd.argtypes = [ctypes.POINTER(PoseDesc), PT, PT, PT, P, P]
+    lib.vsl_mean_inv_depth_workspace_bytes.restype = ctypes.c_size_t
+    lib.vsl_mean_inv_depth_workspace_bytes.argtypes = [I]
+    lib.vsl_mean_inv_depth_fwd.restype = ctypes.c_int
+    lib.vsl_mean_inv_depth_fwd.argtypes = [P, P, P, SZ, I, I, I, F, F, P]
+    lib.vsl_mean_inv_depth_bwd.restype = ctypes.c_int
+    lib.vsl_mean_inv_depth_bwd.argtypes = [P, P, P, I, I, I, I, F, F, P]
     lib.vsl_last_error_string.restype = ctypes.c_char_p
     lib.vsl_last_error_string.argtypes = []
     lib.vsl_version.restype = ctypes.c_int

@@ -11,10 +11,15 @@ Same names, argument order and return values as the reference:
 
 All of them run hand-written HIP kernels through the C-ABI, take part in autograd, accept
 float64 inputs (cast to float32 on load: the reference's images are float64) and, unlike the
-reference, take the batch size from the input instead of the constructor.  The pose helpers
-(``transformation_from_parameters`` etc.) are tiny [B,4,4] maths and stay on stock torch ops.
+reference, take the batch size from the input instead of the constructor.
+
+    transformation_from_parameters(axisangle, translation, invert=False)       layers.py:28
+    poses_from_parameters([...], [...], inverts, t_scale)   every source pose of a step in one launch
+    mean_inverse_depth(disp, min_depth, max_depth)                             Trainer.py:451-452
 """
 from __future__ import annotations
+
+import ctypes
 
 import torch
 import torch.nn as nn
@@ -244,40 +249,130 @@ def get_smooth_loss(disp, img):
     return _Smooth.apply(disp, img)
 
 
-# ------------------------------------------------------------------ pose helpers (stock torch; layers.py:28-103)
-def rot_from_axisangle(vec):
-    """Axis-angle [B,1,3] -> rotation [B,4,4], layers.py:64-103."""
-    angle = torch.norm(vec, 2, 2, True)
-    axis = vec / (angle + 1e-7)
-    ca, sa = torch.cos(angle), torch.sin(angle)
-    C = 1 - ca
-    x, y, z = (axis[..., i].unsqueeze(1) for i in range(3))
-    xy, yz, zx = x * (y * C), y * (z * C), z * (x * C)
-    rows = [[x * (x * C) + ca, xy - z * sa, zx + y * sa],
-            [xy + z * sa, y * (y * C) + ca, yz - x * sa],
-            [zx - y * sa, yz + x * sa, z * (z * C) + ca]]
-    R = torch.zeros(vec.shape[0], 4, 4, dtype=vec.dtype, device=vec.device)
-    for i in range(3):
-        for j in range(3):
-            R[:, i, j] = rows[i][j].reshape(-1)
-    R[:, 3, 3] = 1
-    return R
+# ------------------------------------------------------------------ pose preparation (layers.py:28-103)
+def _rows3(t: torch.Tensor, name: str) -> torch.Tensor:
+    """[B,1,3] or [B,3] (possibly a slice of a [B,F,1,3] network output) as a [B,3] view with unit inner stride."""
+    if not t.is_cuda:
+        raise ValueError("%s must be a GPU tensor (there is no CPU implementation)" % name)
+    if t.dim() not in (2, 3) or t.shape[-1] != 3 or (t.dim() == 3 and t.shape[1] != 1):
+        raise ValueError("%s must be [B,1,3] or [B,3]" % name)
+    r = t.float().reshape(t.shape[0], 3)
+    if r.stride(1) != 1 or (r.shape[0] > 1 and r.stride(0) < 3):
+        r = r.contiguous()
+    return r
 
 
-def get_translation_matrix(translation_vector):
-    """Translation [B,1,3] -> [B,4,4], layers.py:48-61."""
-    t = translation_vector.contiguous().view(-1, 3)
-    M = torch.eye(4, dtype=t.dtype, device=t.device).repeat(t.shape[0], 1, 1)
-    M[:, :3, 3] = t
-    return M
+class _Poses(torch.autograd.Function):
+    """All source poses of a batch in one launch: vsl_pose_fwd / vsl_pose_bwd."""
+
+    @staticmethod
+    def forward(ctx, inverts, t_scale, *params):
+        n = len(params) // 2
+        aa = [_rows3(params[2 * s], "axisangle") for s in range(n)]
+        tr = [_rows3(params[2 * s + 1], "translation") for s in range(n)]
+        B = aa[0].shape[0]
+        if any(x.shape[0] != B for x in aa + tr):
+            raise ValueError("all pose parameters must have the same batch size")
+
+        def common_stride(rows):
+            st = {3 if B == 1 else r.stride(0) for r in rows}
+            if len(st) > 1:
+                return [r.contiguous() for r in rows], 3
+            return rows, st.pop()
+
+        aa, aa_stride = common_stride(aa)
+        tr, tr_stride = common_stride(tr)
+        if t_scale is not None:
+            t_scale = _prep(t_scale, "t_scale").reshape(-1)
+            if t_scale.numel() != B:
+                raise ValueError("t_scale must hold one factor per image")
+        d = _abi.PoseDesc()
+        d.B, d.n_src, d.aa_stride, d.tr_stride = B, n, aa_stride, tr_stride
+        d.invert_mask = sum(1 << s for s in range(n) if inverts[s])
+        for s in range(n):
+            d.axisangle[s], d.translation[s] = aa[s].data_ptr(), tr[s].data_ptr()
+        d.t_scale = _ptr(t_scale)
+        out = [torch.empty(B, 4, 4, dtype=torch.float32, device=aa[0].device) for _ in range(n)]
+        tab = (ctypes.c_void_p * _abi.MAX_SOURCES)(*[o.data_ptr() for o in out])
+        _abi.check(_lib.vsl_pose_fwd(ctypes.byref(d), tab, _stream(aa[0])))
+        ctx.desc, ctx.keep, ctx.n = d, (aa, tr, t_scale), n
+        ctx.shapes = [p.shape for p in params]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *g_T):
+        d, n = ctx.desc, ctx.n
+        aa, tr, t_scale = ctx.keep
+        B, dev = d.B, aa[0].device
+        g = [(x if x is not None else torch.zeros(B, 4, 4, device=dev)).float().contiguous() for x in g_T]
+        g_aa = [torch.empty(B, 3, device=dev) for _ in range(n)]
+        g_tr = [torch.empty(B, 3, device=dev) for _ in range(n)]
+        g_sc = torch.empty(B, device=dev) if t_scale is not None else None
+        tab = lambda ts: (ctypes.c_void_p * _abi.MAX_SOURCES)(*[t.data_ptr() for t in ts])
+        _abi.check(_lib.vsl_pose_bwd(ctypes.byref(d), tab(g), tab(g_aa), tab(g_tr), _ptr(g_sc), _stream(aa[0])))
+        grads = []
+        for s in range(n):
+            grads += [g_aa[s].reshape(ctx.shapes[2 * s]), g_tr[s].reshape(ctx.shapes[2 * s + 1])]
+        return (None, g_sc) + tuple(grads)
+
+
+def poses_from_parameters(axisangles, translations, inverts=None, t_scale=None):
+    """``[transformation_from_parameters(a, t, inv) for a, t, inv in zip(...)]`` (Trainer.py:393,414) in one
+    launch; ``t_scale`` [B] multiplies every translation first (the mean inverse depth of Trainer.py:455)."""
+    n = len(axisangles)
+    if n < 1 or n > _abi.MAX_SOURCES or len(translations) != n:
+        raise ValueError("1..4 (axisangle, translation) pairs")
+    inverts = tuple(bool(v) for v in (inverts if inverts is not None else [False] * n))
+    if len(inverts) != n:
+        raise ValueError("one invert flag per pose")
+    params = []
+    for a, t in zip(axisangles, translations):
+        params += [a, t]
+    return list(_Poses.apply(inverts, t_scale, *params))
 
 
 def transformation_from_parameters(axisangle, translation, invert=False):
-    """(axisangle, translation) -> 4x4 pose, layers.py:28-45."""
-    R = rot_from_axisangle(axisangle)
-    t = translation.clone()
-    if invert:
-        R = R.transpose(1, 2)
-        t = t * -1
-    Tm = get_translation_matrix(t)
-    return torch.matmul(R, Tm) if invert else torch.matmul(Tm, R)
+    """(axisangle [B,1,3], translation [B,1,3]) -> 4x4 pose [B,4,4], layers.py:28-45."""
+    return poses_from_parameters([axisangle], [translation], [invert])[0]
+
+
+class _MeanInvDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, min_depth, max_depth):
+        disp = _prep(disp, "disp")
+        if disp.dim() != 4 or disp.shape[1] != 1:
+            raise ValueError("disp must be [B,1,H,W]")
+        B, _, H, W = disp.shape
+        out = torch.empty(B, dtype=torch.float32, device=disp.device)
+        nbytes = _lib.vsl_mean_inv_depth_workspace_bytes(B)
+        ws = torch.empty(nbytes // 8, dtype=torch.float64, device=disp.device)
+        _abi.check(_lib.vsl_mean_inv_depth_fwd(disp.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, B, H, W,
+                                               float(min_depth), float(max_depth), _stream(disp)))
+        ctx.save_for_backward(disp)
+        ctx.rng = (float(min_depth), float(max_depth))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (disp,) = ctx.saved_tensors
+        B, _, H, W = disp.shape
+        g_disp = torch.empty_like(disp)
+        _abi.check(_lib.vsl_mean_inv_depth_bwd(disp.data_ptr(), g.float().contiguous().data_ptr(), g_disp.data_ptr(), 0,
+                                               B, H, W, ctx.rng[0], ctx.rng[1], _stream(disp)))
+        return g_disp, None, None
+
+
+def mean_inverse_depth(disp, min_depth, max_depth):
+    """Per-image mean of 1/depth, ``(1 / depth).mean(3, True).mean(2, True)`` of Trainer.py:451-452, as [B]."""
+    return _MeanInvDepth.apply(disp, min_depth, max_depth)
+
+
+# ------------------------------------------------------------------ the reference's two helpers, for completeness
+def rot_from_axisangle(vec):
+    """Axis-angle [B,1,3] -> rotation [B,4,4], layers.py:64-103 (pose of zero translation)."""
+    return transformation_from_parameters(vec, torch.zeros_like(vec))
+
+
+def get_translation_matrix(translation_vector):
+    """Translation [B,1,3] -> [B,4,4], layers.py:48-61 (pose of zero rotation)."""
+    return transformation_from_parameters(torch.zeros_like(translation_vector), translation_vector)

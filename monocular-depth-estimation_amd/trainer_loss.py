@@ -15,7 +15,9 @@ need ``generate_images_pred`` to have run); ``generate_images_pred`` materialise
 ("depth",0), ("sample",f), ("color",f) through the per-module kernels for callers that read
 them (validation dumps, depth metrics).  ``opt`` is the reference's option namespace; the
 fields read are: scales, frame_ids, height, width, min_depth, max_depth, v1_multiscale,
-disable_automasking, avg_reprojection, no_ssim, disparity_smoothness.
+disable_automasking, avg_reprojection, no_ssim, disparity_smoothness, pose_model_type.
+
+    pose_outputs(axisangle, translation) -> {("cam_T_cam",f), ...}   Trainer.py:388-393,408-414
 """
 from __future__ import annotations
 
@@ -25,7 +27,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _abi
-from .layers import BackprojectDepth, Project3D, SSIM, disp_to_depth, get_smooth_loss, grid_sample_border
+from .layers import (BackprojectDepth, Project3D, SSIM, disp_to_depth, get_smooth_loss, grid_sample_border,
+                     mean_inverse_depth, poses_from_parameters)
 from .ops import fused_view_synthesis_loss, fused_view_synthesis_loss_heads
 
 
@@ -47,6 +50,44 @@ class ViewSynthesisLoss:
     def _pose(self, inputs, outputs, f):
         return inputs["stereo_T"] if f == "s" else outputs[("cam_T_cam", f)]
 
+    def _poses(self, inputs, outputs, disp):
+        """The pose matrix of every source as the warp uses it.  With the "posecnn" pose model the reference
+        rebuilds it from the parameters, the translation multiplied by the image's mean inverse depth
+        (Trainer.py:446-455): one reduction and one pose launch here, differentiable down to disp."""
+        srcs = self._sources()
+        if getattr(self.opt, "pose_model_type", "shared") != "posecnn":
+            return [self._pose(inputs, outputs, f) for f in srcs]
+        if "s" in srcs:
+            raise ValueError("pose_model_type='posecnn' has no stereo branch in the reference (Trainer.py:446-455)")
+        scale = mean_inverse_depth(disp, self.opt.min_depth, self.opt.max_depth)
+        return poses_from_parameters([outputs[("axisangle", f)][:, 0] for f in srcs],
+                                     [outputs[("translation", f)][:, 0] for f in srcs],
+                                     [f < 0 for f in srcs], t_scale=scale)
+
+    # ------------------------------------------------------------------ Trainer.py:388-393,408-414
+    def pose_outputs(self, axisangle, translation) -> Dict:
+        """The dict entries Trainer.predict_pose adds for the temporal sources, all matrices in one launch.
+        "all" input mode (Trainer.py:408-414): one pose-network output pair [B,F,1,3], source i uses slice i,
+        no inversion.  "pairs" mode (Trainer.py:388-393): dicts frame_id -> [B,1,1,3] network outputs, slice 0,
+        inverted for negative frame ids."""
+        srcs = [f for f in self._sources() if f != "s"]
+        out = {}
+        if isinstance(axisangle, dict):
+            aa = [axisangle[f][:, 0] for f in srcs]
+            tr = [translation[f][:, 0] for f in srcs]
+            inv = [f < 0 for f in srcs]
+            for f in srcs:
+                out[("axisangle", f)], out[("translation", f)] = axisangle[f], translation[f]
+        else:
+            aa = [axisangle[:, i] for i, _ in enumerate(srcs)]
+            tr = [translation[:, i] for i, _ in enumerate(srcs)]
+            inv = [False] * len(srcs)
+            for f in srcs:
+                out[("axisangle", f)], out[("translation", f)] = axisangle, translation
+        for f, T in zip(srcs, poses_from_parameters(aa, tr, inv)):
+            out[("cam_T_cam", f)] = T
+        return out
+
     def _full_res_disp(self, outputs):
         disp = outputs[("disp", 0)]
         if not getattr(self.opt, "v1_multiscale", False) and tuple(disp.shape[2:]) != (self.opt.height, self.opt.width):
@@ -59,8 +100,8 @@ class ViewSynthesisLoss:
         _, depth = disp_to_depth(disp, self.opt.min_depth, self.opt.max_depth)
         outputs[("depth", 0)] = depth
         points = self.backproject_depth(depth, inputs["inv_K"])
-        for f in self._sources():
-            grid = self.project_3d(points, inputs["K"], self._pose(inputs, outputs, f))
+        for f, T in zip(self._sources(), self._poses(inputs, outputs, disp)):
+            grid = self.project_3d(points, inputs["K"], T)
             outputs[("sample", f)] = grid
             outputs[("color", f)] = grid_sample_border(inputs[("image", f)], grid)
             if not self.opt.disable_automasking:
@@ -86,7 +127,7 @@ class ViewSynthesisLoss:
         self._step += 1
         out, ident = fused_view_synthesis_loss(
             disp, inputs[("image", 0)], [inputs[("image", f)] for f in srcs], inputs["K"], inputs["inv_K"],
-            [self._pose(inputs, outputs, f) for f in srcs], noise,
+            self._poses(inputs, outputs, disp), noise,
             automask=automask, avg_reprojection=opt.avg_reprojection, no_ssim=opt.no_ssim,
             scale_weights=scale_w, inv_num_scales=1.0 / self.num_scales,
             warp_scale=self.photometric_scale if photometric_scale is None else photometric_scale,

@@ -9,7 +9,8 @@ replaced by empty modules, ``Tensor.cuda`` is neutralised because this container
 has no GPU, and ``torch.randn`` is pinned to the recorded tie-break noise while
 ``compute_losses`` runs (Trainer.py:589 draws it from the CPU generator).
 
-    python oracle/make_golden.py            # rewrites tests/golden/*.npz
+    python oracle/make_golden.py               # rewrites tests/golden/*.npz
+    python oracle/make_golden.py --pose-only   # only the pose-preparation fixtures
 
 Every file holds: the inputs (fp32 values; the reference is fed their float64
 copies, as its data loader would produce), every intermediate the reference
@@ -58,7 +59,7 @@ def make_trainer(cls, layers, B, H, W, c):
     tr = object.__new__(cls)
     tr.opt = types.SimpleNamespace(
         scales=list(c["scales"]), frame_ids=list(c["frame_ids"]), v1_multiscale=False, height=H, width=W,
-        min_depth=0.1, max_depth=100.0, pose_model_type="shared",
+        min_depth=0.1, max_depth=100.0, pose_model_type=c.get("pose_model_type", "shared"),
         disable_automasking=not c["automask"], predictive_mask=False,
         avg_reprojection=c["avg_reprojection"], no_ssim=c["no_ssim"], disparity_smoothness=1e-3)
     tr.num_scales = 1
@@ -177,11 +178,94 @@ def run_case(c, layers, trainer, distil, out_dir):
     return path, float(rec["loss"]), float(np.abs(rec["grad_disp"]).sum())
 
 
+def run_pose_cases(layers, trainer, out_dir):
+    """Pose preparation: layers.transformation_from_parameters on slices of a [B,F,1,3] network output, both
+    invert settings, with gradients for a fixed upstream g_T; and one loss case in the "posecnn" mode, where
+    Trainer.generate_images_pred rebuilds T from the parameters and the mean inverse depth (Trainer.py:446-455)."""
+    B, F = 6, 2
+    scale = torch.tensor([0.01, 0.01, 0.3, 0.3, 2.0, 1.0]).view(B, 1, 1, 1)
+    aa0 = torch.from_numpy(synth.normal(21, (B, F, 1, 3)).astype(np.float32)) * scale
+    tr0 = torch.from_numpy(synth.normal(22, (B, F, 1, 3)).astype(np.float32)) * scale
+    aa0[5, 0] = 0.0                                   # zero rotation: angle = 0, axis = 0 / 1e-7
+    g_T = torch.from_numpy(synth.normal(23, (F, 2, B, 4, 4)).astype(np.float32))
+    rec = {"axisangle": aa0.numpy(), "translation": tr0.numpy(), "g_T": g_T.numpy()}
+    for i in range(F):
+        for inv in (0, 1):
+            aa, tr = aa0.clone().requires_grad_(True), tr0.clone().requires_grad_(True)
+            T = layers.transformation_from_parameters(aa[:, i], tr[:, i], invert=bool(inv))
+            (T * g_T[i, inv]).sum().backward()
+            rec["T_%d_%d" % (i, inv)] = T.detach().numpy()
+            rec["g_axisangle_%d_%d" % (i, inv)] = aa.grad.numpy()
+            rec["g_translation_%d_%d" % (i, inv)] = tr.grad.numpy()
+    os.makedirs(os.path.join(out_dir, "pose"), exist_ok=True)
+    np.savez_compressed(os.path.join(out_dir, "pose", "pose_params.npz"), **rec)
+
+    # The seed is the first one from 18 on for which no pixel's two smallest candidates of the per-pixel minimum
+    # are closer than 1e-6: the device evaluates sin / cos and the mean inverse depth with other last bits than
+    # this host, and a closer tie could legitimately select the other candidate there.
+    for seed in range(18, 60):
+        c = dict(name="b2_24x80_posecnn", B=2, H=24, W=80, frame_ids=[0, -1, 1], automask=True, seed=seed,
+                 avg_reprojection=False, no_ssim=False, scales=[0], pose_model_type="posecnn")
+        Bc, H, W, fids = c["B"], c["H"], c["W"], c["frame_ids"]
+        data = synth.make_batch(Bc, H, W, fids, seed=c["seed"])
+        noise = data["noise"].contiguous()
+        tr_ = make_trainer(trainer.Trainer, layers, Bc, H, W, c)
+        inputs = {"K": data["K"], "inv_K": data["inv_K"]}
+        for f in fids:
+            inputs[("image", f)] = data[("image", f)].double()
+        disp = data[("disp", 0)].clone().requires_grad_(True)
+        outputs = {("disp", 0): disp}
+        params = {}
+        for j, f in enumerate(fids[1:]):
+            aa = (torch.from_numpy(synth.normal(30 + j, (Bc, 1, 1, 3)).astype(np.float32)) * 0.01).requires_grad_(True)
+            tv = (torch.from_numpy(synth.normal(40 + j, (Bc, 1, 1, 3)).astype(np.float32)) * 0.01).requires_grad_(True)
+            params[f] = (aa, tv)
+            outputs[("axisangle", f)], outputs[("translation", f)] = aa, tv
+            outputs[("cam_T_cam", f)] = layers.transformation_from_parameters(aa[:, 0], tv[:, 0], invert=(f < 0))
+        real_randn = torch.randn
+        torch.randn = lambda *a, **k: noise.clone()
+        try:
+            tr_.generate_images_pred(inputs, outputs)
+            losses = tr_.compute_losses(inputs, outputs)
+        finally:
+            torch.randn = real_randn
+        with torch.no_grad():
+            tgt = inputs[("image", 0)]
+            cand = [tr_.compute_reprojection_loss(inputs[("image", f)], tgt) for f in fids[1:]]
+            cand = torch.cat(cand, 1) + noise.double() * 0.00001
+            cand = torch.cat([cand] + [tr_.compute_reprojection_loss(outputs[("color", f)], tgt) for f in fids[1:]], 1)
+            two = torch.topk(cand, 2, dim=1, largest=False).values
+            margin = float((two[:, 1] - two[:, 0]).min())
+        if margin >= 1e-6:
+            break
+    else:
+        raise RuntimeError("no seed without near-ties found")
+    losses["loss"].backward()
+    rec = {"config": np.array(json.dumps(c)), "disp": data[("disp", 0)].numpy(), "K": data["K"].numpy(),
+           "inv_K": data["inv_K"].numpy(), "noise": noise.numpy(), "loss": losses["loss"].detach().numpy(),
+           "grad_disp": disp.grad.numpy(), "identity_selection": outputs["identity_selection"].numpy()}
+    with torch.no_grad():
+        rec["mean_inv_depth"] = (1 / outputs[("depth", 0)]).mean(3, True).mean(2, True).numpy()
+    for f in fids:
+        rec["image_%s" % f] = data[("image", f)].numpy()
+    for f in fids[1:]:
+        rec["axisangle_%s" % f] = params[f][0].detach().numpy()
+        rec["translation_%s" % f] = params[f][1].detach().numpy()
+        rec["g_axisangle_%s" % f] = params[f][0].grad.numpy()
+        rec["g_translation_%s" % f] = params[f][1].grad.numpy()
+        rec["sample_%s" % f] = outputs[("sample", f)].detach().numpy()
+    np.savez_compressed(os.path.join(out_dir, "pose", c["name"] + ".npz"), **rec)
+    print("pose/pose_params.npz, %s.npz  seed=%d margin=%.2e loss=%.10f" % (c["name"], seed, margin, float(rec["loss"])))
+
+
 def main():
     torch.set_num_threads(1)   # deterministic summation order on the CPU
     layers, trainer, distil = load_reference()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    run_pose_cases(layers, trainer, out_dir)
+    if "--pose-only" in sys.argv:
+        return
     for c in CASES:
         path, loss, g = run_case(c, layers, trainer, distil, out_dir)
         print("%-40s loss=%.10f |grad_disp|_1=%.6e  %6.1f KB" % (

@@ -57,6 +57,7 @@ class LossConfig:
     v1_multiscale: bool = False
     warp_scale: float = 1.0             # 0.9 in Trainer_distilation.compute_losses
     num_scales: int = 1                 # Trainer.py:33 (divisor of the total)
+    pose_model_type: str = "shared"     # "posecnn": T rebuilt from the parameters x mean inverse depth
 
     @property
     def sources(self) -> List:
@@ -200,6 +201,10 @@ def view_synthesis(inputs: Dict, outputs: Dict, cfg: LossConfig) -> None:
         outputs[("depth", 0)] = depth
         for f in cfg.sources:
             T = inputs["stereo_T"] if f == "s" else outputs[("cam_T_cam", f)]
+            if cfg.pose_model_type == "posecnn":                    # Trainer.py:446-455
+                mean_inv_depth = (1 / depth).mean(3, True).mean(2, True)
+                T = transformation_from_parameters(outputs[("axisangle", f)][:, 0],
+                                                   outputs[("translation", f)][:, 0] * mean_inv_depth[:, 0], f < 0)
             pts = backproject(depth, inputs["inv_K"])
             grid = project(pts, inputs["K"], T, cfg.height, cfg.width)
             outputs[("sample", f)] = grid

@@ -80,3 +80,31 @@ def test_head_validation_without_gpu():
     fill(heads[1])
     assert abi.lib.vsl_loss_backward_heads(ctypes.byref(d), heads, 2, None) == -1 and b"NO_GRAD" in err()
     assert abi.lib.vsl_loss_forward_heads(None, heads, 2, None) == -1
+
+
+def test_pose_descriptor_validation_without_gpu():
+    """vsl_pose_fwd / vsl_pose_bwd / vsl_mean_inv_depth_* reject malformed arguments before any launch."""
+    import mde_amd._abi as abi
+    assert ctypes.sizeof(abi.PoseDesc) == 96
+    fake = 0x1000
+    d = abi.PoseDesc()
+    tab = (ctypes.c_void_p * abi.MAX_SOURCES)(fake, fake, fake, fake)
+    err = lambda: abi.lib.vsl_last_error_string()
+    d.B, d.n_src, d.aa_stride, d.tr_stride = 2, 0, 3, 3
+    assert abi.lib.vsl_pose_fwd(ctypes.byref(d), tab, None) == -1 and b"n_src" in err()
+    d.n_src = 5
+    assert abi.lib.vsl_pose_fwd(ctypes.byref(d), tab, None) == -1
+    d.n_src, d.aa_stride = 2, 2
+    assert abi.lib.vsl_pose_fwd(ctypes.byref(d), tab, None) == -1 and b"stride" in err()
+    d.aa_stride = 6
+    assert abi.lib.vsl_pose_fwd(ctypes.byref(d), tab, None) == -1 and b"null" in err()      # parameter pointers unset
+    d.axisangle[0] = d.axisangle[1] = d.translation[0] = d.translation[1] = fake
+    assert abi.lib.vsl_pose_fwd(ctypes.byref(d), None, None) == -1
+    assert abi.lib.vsl_pose_bwd(ctypes.byref(d), None, tab, tab, None, None) == -1
+    d.B = 0
+    assert abi.lib.vsl_pose_fwd(ctypes.byref(d), tab, None) == -1
+    assert abi.lib.vsl_pose_fwd(None, tab, None) == -1
+    assert abi.lib.vsl_mean_inv_depth_workspace_bytes(12) == 12 * 32 * 8
+    assert abi.lib.vsl_mean_inv_depth_fwd(fake, fake, fake, 8, 12, 192, 640, 0.1, 100.0, None) == -2
+    assert abi.lib.vsl_mean_inv_depth_fwd(fake, fake, fake, 1 << 20, 12, 0, 640, 0.1, 100.0, None) == -1
+    assert abi.lib.vsl_mean_inv_depth_bwd(fake, None, fake, 0, 12, 192, 640, 0.1, 100.0, None) == -1

@@ -11,7 +11,10 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import build_dicts, case_names, load_case
+import json
+import os
+
+from golden_util import GOLDEN_DIR, build_dicts, case_names, load_case
 from oracle import vsl_oracle as O
 
 
@@ -75,3 +78,53 @@ def test_pose_helper_matches_synth():
     np.testing.assert_allclose(M.numpy(), M2, atol=1e-6)
     Mi = O.transformation_from_parameters(aa, tr, invert=True)
     np.testing.assert_allclose(torch.matmul(M, Mi).numpy(), np.tile(np.eye(4), (4, 1, 1)), atol=1e-6)
+
+
+def test_pose_parameters_match_reference_fixture():
+    """layers.transformation_from_parameters of the reference on slices of a [B,F,1,3] output, both invert
+    settings, values and gradients (fixture written by oracle/make_golden.py from the reference import)."""
+    z = np.load(os.path.join(GOLDEN_DIR, "pose", "pose_params.npz"))
+    F_ = z["axisangle"].shape[1]
+    for i in range(F_):
+        for inv in (0, 1):
+            aa = torch.from_numpy(z["axisangle"]).clone().requires_grad_(True)
+            tr = torch.from_numpy(z["translation"]).clone().requires_grad_(True)
+            T = O.transformation_from_parameters(aa[:, i], tr[:, i], invert=bool(inv))
+            (T * torch.from_numpy(z["g_T"][i, inv])).sum().backward()
+            np.testing.assert_allclose(T.detach().numpy(), z["T_%d_%d" % (i, inv)], rtol=0, atol=1e-7)
+            np.testing.assert_allclose(aa.grad.numpy(), z["g_axisangle_%d_%d" % (i, inv)], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(tr.grad.numpy(), z["g_translation_%d_%d" % (i, inv)], rtol=1e-6, atol=1e-7)
+
+
+def test_posecnn_mode_matches_reference_fixture():
+    """Trainer.generate_images_pred in the "posecnn" mode (Trainer.py:446-455): T from the parameters and the
+    per-image mean inverse depth; loss and the gradients of disparity and pose parameters."""
+    z = np.load(os.path.join(GOLDEN_DIR, "pose", "b2_24x80_posecnn.npz"))
+    c = json.loads(str(z["config"]))
+    fids = c["frame_ids"]
+    cfg = O.LossConfig(frame_ids=fids, scales=c["scales"], height=c["H"], width=c["W"], automask=True,
+                       pose_model_type="posecnn")
+    inputs = {"K": torch.from_numpy(z["K"]), "inv_K": torch.from_numpy(z["inv_K"])}
+    for f in fids:
+        inputs[("image", f)] = torch.from_numpy(z["image_%s" % f]).double()
+    disp = torch.from_numpy(z["disp"]).clone().requires_grad_(True)
+    outputs = {("disp", 0): disp}
+    params = {}
+    for f in fids[1:]:
+        aa = torch.from_numpy(z["axisangle_%s" % f]).clone().requires_grad_(True)
+        tr = torch.from_numpy(z["translation_%s" % f]).clone().requires_grad_(True)
+        params[f] = (aa, tr)
+        outputs[("axisangle", f)], outputs[("translation", f)] = aa, tr
+        outputs[("cam_T_cam", f)] = O.transformation_from_parameters(aa[:, 0], tr[:, 0], invert=(f < 0))
+    losses = O.loss_forward_backward(inputs, outputs, cfg, torch.from_numpy(z["noise"]))
+    assert abs(losses["loss"].item() - float(z["loss"])) <= 1e-7 * abs(float(z["loss"]))
+    np.testing.assert_array_equal(outputs["identity_selection"].numpy(), z["identity_selection"])
+    tol = 1e-5
+
+    def close(a, b):
+        return np.linalg.norm(a - b) <= tol * np.linalg.norm(b)
+
+    assert close(disp.grad.numpy(), z["grad_disp"])
+    for f in fids[1:]:
+        assert close(params[f][0].grad.numpy(), z["g_axisangle_%s" % f])
+        assert close(params[f][1].grad.numpy(), z["g_translation_%s" % f])
