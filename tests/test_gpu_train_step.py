@@ -1,0 +1,89 @@
+"""TrainStep (process_batch / predict_pose / train_step in the reference's order, Python/Trainer.py:217-243,
+328-416) on the GPU with small stand-in networks: the loss equals the oracle's on the same network outputs,
+gradients reach every trainable parameter, and a few optimizer steps reduce the loss."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vsl_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(pose_model_input="all", B=2, H=32, W=96):
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import synthetic_train as ex
+    import mde_amd.synth as synth
+    from mde_amd.trainer_step import TrainStep
+    opt = types.SimpleNamespace(
+        scales=[0, 1], frame_ids=[0, -1, 1], height=H, width=W, min_depth=0.1, max_depth=100.0, v1_multiscale=False,
+        disable_automasking=False, avg_reprojection=False, no_ssim=False, disparity_smoothness=1e-3,
+        pose_model_type="shared", pose_model_input=pose_model_input)
+    torch.manual_seed(3)
+    n_pose = 2 if pose_model_input == "pairs" else len(opt.frame_ids)
+    models = {"encoder": ex.TinyEncoder().to(DEV), "depth": ex.TinyDepthDecoder(opt.scales).to(DEV),
+              "pose": ex.TinyPoseDecoder(n_pose).to(DEV)}
+    if pose_model_input == "pairs":        # one (axisangle, translation) per call, as networks.PoseDecoder(2, 1) gives
+        inner = models["pose"]
+        models["pose"] = _FirstFrame(inner).to(DEV)
+    params = [p for m in models.values() for p in m.parameters()]
+    step = TrainStep(opt, models, torch.optim.Adam(params, 1e-3))
+    data = synth.make_batch(B, H, W, opt.frame_ids, seed=21)
+    inputs = {"K": data["K"].to(DEV), "inv_K": data["inv_K"].to(DEV)}
+    for f in opt.frame_ids:
+        inputs[("image", f)] = data[("image", f)].to(DEV)
+        inputs[("image_aug", f)] = inputs[("image", f)]
+    return opt, models, params, step, data, inputs
+
+
+class _FirstFrame(torch.nn.Module):
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def forward(self, feats):
+        a, t = self.inner(feats)
+        return a[:, :1], t[:, :1]
+
+
+@pytest.mark.parametrize("mode", ["all", "pairs"])
+def test_process_batch_matches_oracle_on_the_same_network_outputs(mode):
+    opt, models, params, step, data, inputs = _setup(mode)
+    noise = data["noise"].to(DEV)
+    outputs, losses = step.process_batch(inputs, noise)
+    losses["loss"].backward()
+    assert set(losses) == {"loss", "loss/0", "loss/1"}
+    for f in (-1, 1):
+        assert outputs[("cam_T_cam", f)].shape == (2, 4, 4)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    assert sum(float(p.grad.abs().sum()) for p in models["pose"].parameters()) > 0
+    # the oracle on the network outputs (float32 disparity, parameters), gradients with respect to those outputs
+    cfg = O.LossConfig(frame_ids=opt.frame_ids, scales=opt.scales, height=opt.height, width=opt.width, automask=True)
+    o_in = {"K": data["K"], "inv_K": data["inv_K"]}
+    for f in opt.frame_ids:
+        o_in[("image", f)] = data[("image", f)].double()
+    disp = outputs[("disp", 0)].detach().cpu().requires_grad_(True)
+    o_out = {("disp", 0): disp}
+    for i, f in enumerate(opt.frame_ids[1:]):
+        aa = outputs[("axisangle", f)].detach().cpu()
+        tr = outputs[("translation", f)].detach().cpu()
+        k = 0 if mode == "pairs" else i
+        o_out[("cam_T_cam", f)] = O.transformation_from_parameters(aa[:, k], tr[:, k], invert=(mode == "pairs" and f < 0))
+    ref = O.loss_forward_backward(o_in, o_out, cfg, data["noise"])
+    for k in losses:
+        assert abs(losses[k].item() - ref[k].item()) <= 1e-5 * abs(ref[k].item()), k
+
+
+def test_train_steps_reduce_the_loss():
+    opt, models, params, step, data, inputs = _setup("all")
+    before = [p.detach().clone() for p in params]
+    values = [step.train_step(inputs, data["noise"].to(DEV))[1]["loss"].item() for _ in range(8)]
+    assert all(np.isfinite(values))
+    assert values[-1] < values[0]
+    assert any(not torch.equal(a, b) for a, b in zip(before, params))
