@@ -191,6 +191,12 @@ struct __attribute__((packed, aligned(4))) TexelPair {
   float lo, hi;
 };
 VSL_DEV TexelPair load_texel_pair(const float* p) { return *reinterpret_cast<const TexelPair*>(p); }
+// The same from a uniform plane base and a 32-bit byte offset (planes are smaller than 2^30 bytes: H*W < 2^28 is
+// checked on the host), which the compiler can issue as scalar base + 32-bit vector offset without 64-bit
+// address arithmetic per load; one offset register serves the three colour planes.
+VSL_DEV TexelPair load_texel_pair_at(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const TexelPair*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 struct Taps {
   int i0, i1;
@@ -587,7 +593,7 @@ struct Fused {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float* pc = sp + (size_t)c * HW;
-          const TexelPair a = load_texel_pair(pc + o0), b = load_texel_pair(pc + o1);
+          const TexelPair a = load_texel_pair_at(pc, o0 << 2), b = load_texel_pair_at(pc, o1 << 2);
           const float v00 = xs ? a.lo : a.hi, v01 = a.hi;
           const float v10 = xs ? b.lo : b.hi, v11 = b.hi;
           lds[OFF_WRP + (s * 3 + c) * P2 + p2] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
@@ -731,9 +737,10 @@ struct Fused {
       phase3_smooth(kp, hv, bk, tid, lds, st);
       return;
     }
-    if (ip < 0 || ip >= TW / 2) return;
     const bool remote = row < 2;
     const int iy = remote ? row + TH - 2 : row - 2;
+    // one combined test (no short-circuit): nested early exits make the compiler re-zero all partial sums at every level
+    if ((int)(ip < 0) | (int)(ip >= TW / 2) | (int)(bk.y0 + iy >= kp.H) | (int)(bk.x0 + 2 * ip >= kp.W)) return;
     Chain chn[2][S];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
@@ -748,9 +755,7 @@ struct Fused {
         }
       }
     const int jy = bk.y0 + iy;
-    if (jy >= H) return;
     const int jx0 = bk.x0 + 2 * ip;
-    if (jx0 >= W) return;
     const bool ok[2] = {true, jx0 + 1 < W};
     const float* coef = lds + OFF_COEF;
     const float* sel = lds + OFF_COEF + NSET * 9 * P1;
@@ -877,7 +882,7 @@ struct Fused {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float* pc = src_image(kp, s) + ((size_t)bk.b * 3 + c) * HW;
-            const TexelPair a = load_texel_pair(pc + o0), b = load_texel_pair(pc + o1);
+            const TexelPair a = load_texel_pair_at(pc, o0 << 2), b = load_texel_pair_at(pc, o1 << 2);
             tv[k][c][0] = xs ? a.lo : a.hi;
             tv[k][c][1] = a.hi;
             tv[k][c][2] = xs ? b.lo : b.hi;
