@@ -247,6 +247,33 @@ int vsl_mean_inv_depth_fwd(const float* disp, float* out, void* workspace, size_
 int vsl_mean_inv_depth_bwd(const float* disp, const float* g_out, float* g_disp, int accumulate, int B, int H, int W,
                            float min_depth, float max_depth, void* stream);
 
+/*
+ * Feature warping at a coarse scale (Python/Train_distillation_new.py:1159-1182, the same block in
+ * Python/train_controlled_diffusion.py:1106-1129): disp_to_depth -> BackprojectDepth -> Project3D ->
+ * F.grid_sample(feats, grid, padding_mode="border") of a C-channel float32 feature map that requires a
+ * gradient, fused into one pass (the points and the grid are never written out).  `disp` is the disparity
+ * already resized to H x W (the F.interpolate of :1159 stays with the caller); K, inv_K are used as given
+ * (the reference passes the full-resolution intrinsics at every scale).
+ */
+typedef struct vsl_warp_desc {
+  int32_t B, C, H, W;
+  float min_depth, max_depth, eps;   /* eps = 1e-7 (Python/layers.py:180) */
+  uint32_t reserved;
+  const float* feats;                /* [B,C,H,W] */
+  const float* disp;                 /* [B,1,H,W] */
+  const float* K;                    /* [B,4,4]   */
+  const float* inv_K;                /* [B,4,4]   */
+  const float* T;                    /* [B,4,4]   */
+} vsl_warp_desc;
+
+size_t vsl_warp_features_workspace_bytes(const vsl_warp_desc* desc);
+/* out [B,C,H,W]; sample: the sampling grid [B,H,W,2] or NULL. */
+int vsl_warp_features_fwd(const vsl_warp_desc* desc, float* out, float* sample, void* stream);
+/* g_out [B,C,H,W] -> g_feats [B,C,H,W] (float atomics: last bits depend on arrival order), g_disp [B,1,H,W],
+ * g_T [B,4,4]; each may be NULL.  workspace: vsl_warp_features_workspace_bytes(desc) bytes, 8-byte aligned. */
+int vsl_warp_features_bwd(const vsl_warp_desc* desc, const float* g_out, float* g_feats, float* g_disp, float* g_T,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* Library version, e.g. 100 for 0.1.0. */
 int vsl_version(void);
 

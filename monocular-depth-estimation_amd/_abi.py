@@ -27,6 +27,7 @@ EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", 
            "vsl_grid_sample_fwd", "vsl_grid_sample_bwd", "vsl_ssim_fwd", "vsl_ssim_bwd",
            "vsl_smooth_workspace_bytes", "vsl_smooth_fwd", "vsl_smooth_bwd",
            "vsl_pose_fwd", "vsl_pose_bwd",
+           "vsl_warp_features_workspace_bytes", "vsl_warp_features_fwd", "vsl_warp_features_bwd",
            "vsl_mean_inv_depth_workspace_bytes", "vsl_mean_inv_depth_fwd", "vsl_mean_inv_depth_bwd",
            "vsl_debug_fused_occupancy", "vsl_debug_time_fused", "vsl_last_error_string", "vsl_version")
 
@@ -63,6 +64,16 @@ class PoseDesc(ctypes.Structure):
         ("invert_mask", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
         ("axisangle", ctypes.c_void_p * MAX_SOURCES), ("translation", ctypes.c_void_p * MAX_SOURCES),
         ("t_scale", ctypes.c_void_p),
+    ]
+
+
+class WarpDesc(ctypes.Structure):
+    """Mirror of ``vsl_warp_desc`` (include/vsloss.h)."""
+    _fields_ = [
+        ("B", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("min_depth", ctypes.c_float), ("max_depth", ctypes.c_float), ("eps", ctypes.c_float), ("reserved", ctypes.c_uint32),
+        ("feats", ctypes.c_void_p), ("disp", ctypes.c_void_p), ("K", ctypes.c_void_p), ("inv_K", ctypes.c_void_p),
+        ("T", ctypes.c_void_p),
     ]
 
 
@@ -123,6 +134,12 @@ def _load():
     lib.vsl_pose_fwd.argtypes = [ctypes.POINTER(PoseDesc), PT, P]
     lib.vsl_pose_bwd.restype = ctypes.c_int
     lib.vsl_pose_bwd.argtypes = [ctypes.POINTER(PoseDesc), PT, PT, PT, P, P]
+    lib.vsl_warp_features_workspace_bytes.restype = ctypes.c_size_t
+    lib.vsl_warp_features_workspace_bytes.argtypes = [ctypes.POINTER(WarpDesc)]
+    lib.vsl_warp_features_fwd.restype = ctypes.c_int
+    lib.vsl_warp_features_fwd.argtypes = [ctypes.POINTER(WarpDesc), P, P, P]
+    lib.vsl_warp_features_bwd.restype = ctypes.c_int
+    lib.vsl_warp_features_bwd.argtypes = [ctypes.POINTER(WarpDesc), P, P, P, P, P, SZ, P]
     lib.vsl_mean_inv_depth_workspace_bytes.restype = ctypes.c_size_t
     lib.vsl_mean_inv_depth_workspace_bytes.argtypes = [I]
     lib.vsl_mean_inv_depth_fwd.restype = ctypes.c_int

@@ -194,6 +194,12 @@ VSL_DEV TexelPair load_texel_pair(const float* p) { return *reinterpret_cast<con
 // The same from a uniform plane base and a 32-bit byte offset (planes are smaller than 2^30 bytes: H*W < 2^28 is
 // checked on the host), which the compiler can issue as scalar base + 32-bit vector offset without 64-bit
 // address arithmetic per load; one offset register serves the three colour planes.
+VSL_DEV float load_f32_at(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+VSL_DEV void store_f32_at(float* base, unsigned byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
 VSL_DEV TexelPair load_texel_pair_at(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const TexelPair*>(reinterpret_cast<const char*>(base) + byte_off);
 }
@@ -548,10 +554,10 @@ struct Fused {
       const int px = reflect_clamp(bk.x0 - HALO + rx0 + k, W);
       const int p2 = ry * R2W + rx0 + k;
       const unsigned pix = (unsigned)py * (unsigned)W + (unsigned)px;
-      const float d = dispb[pix];
+      const float d = load_f32_at(dispb, pix << 2);
       lds[OFF_DSP + p2] = d;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) lds[OFF_TGT + c * P2 + p2] = (tgtb + (size_t)c * HW)[pix];
+      for (int c = 0; c < 3; ++c) lds[OFF_TGT + c * P2 + p2] = load_f32_at(tgtb + (size_t)c * HW, pix << 2);
 
       // disp_to_depth and the back-projected ray, layers.py:21-25,163-169
       const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
@@ -644,7 +650,7 @@ struct Fused {
     if (kp.automask) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
-        if (valid[k]) best[k] = kp.idmin[(size_t)bk.b * HW + (size_t)gy * kp.W + gx0 + k];
+        if (valid[k]) best[k] = load_f32_at(kp.idmin + (size_t)bk.b * HW, ((unsigned)gy * (unsigned)kp.W + (unsigned)(gx0 + k)) << 2);
     }
     float win[2] = {-1.0f, -1.0f};
     float rsum[2] = {0.0f, 0.0f};
@@ -719,7 +725,8 @@ struct Fused {
       if (interior[k]) {
         st.photo += best[k];
         if (kp.automask && hv.ident_sel)
-          hv.ident_sel[((size_t)bk.b * kp.H + gy) * kp.W + gx0 + k] = (win[k] >= 0.0f) ? 1.0f : 0.0f;
+          store_f32_at(hv.ident_sel + (size_t)bk.b * HW, ((unsigned)gy * (unsigned)kp.W + (unsigned)(gx0 + k)) << 2,
+                       (win[k] >= 0.0f) ? 1.0f : 0.0f);
       }
     }
   }
@@ -949,7 +956,7 @@ struct Fused {
     if (hv.want_grad) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
-        if (ok[k]) hv.gphoto[(size_t)bk.b * HW + (size_t)jy * W + jx0 + k] = g_disp[k];
+        if (ok[k]) store_f32_at(hv.gphoto + (size_t)bk.b * HW, ((unsigned)jy * (unsigned)W + (unsigned)(jx0 + k)) << 2, g_disp[k]);
     }
   }
 
@@ -1002,7 +1009,7 @@ struct Fused {
         if (t == 2) st.part[3] = fmaf(w, fabsf(diff), st.part[3]);
       }
       st.part[1] += d0;
-      if (hv.want_grad) hv.gedge[(size_t)bk.b * HW + (size_t)jy * W + jx] = e;
+      if (hv.want_grad) store_f32_at(hv.gedge + (size_t)bk.b * HW, ((unsigned)jy * (unsigned)W + (unsigned)jx) << 2, e);
     }
   }
 

@@ -420,9 +420,243 @@ int check_hw(int B, int H, int W) {
   return VSL_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Feature warping at a coarse scale (Python/Train_distillation_new.py:1159-1182): disp -> depth -> backproject ->
+// project -> bilinear sample of a C-channel feature map that carries a gradient, in one pass.  Coordinates follow
+// the same rounding recipe as the kernels above, so they equal the module-by-module result bit for bit.
+// Grid: (pixel blocks, channel groups, images); a thread handles one pixel and `cg` consecutive channels.
+// ---------------------------------------------------------------------------
+struct WarpArgs {
+  const float* feats;
+  const float* disp;
+  const float* K;
+  const float* inv_K;
+  const float* T;
+  int C, H, W, cg;
+  float a_disp, c_disp, eps;
+};
+
+struct WarpPixel {
+  float X[3];    // back-projected point
+  float ray[3];  // inv_K[:3,:3] (x, y, 1)
+  float cam[3];  // P (X, 1)
+  float sd;      // scaled disparity
+  float gx, gy;  // normalised sampling coordinates
+};
+
+__device__ __forceinline__ WarpPixel warp_pixel(const WarpArgs& a, const float P[12], int b, int p) {
+  WarpPixel o;
+  const float d = a.disp[(size_t)b * a.H * a.W + p];
+  o.sd = VSL_FADD(a.a_disp, VSL_FMUL(a.c_disp, d));
+  const float depth = VSL_FDIV(1.0f, o.sd);
+  ray(a.inv_K + 16 * b, (float)(p % a.W), (float)(p / a.W), o.ray);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o.X[i] = VSL_FMUL(depth, o.ray[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float v = VSL_FMUL(P[i * 4 + 0], o.X[0]);
+    v = fmaf(P[i * 4 + 1], o.X[1], v);
+    v = fmaf(P[i * 4 + 2], o.X[2], v);
+    o.cam[i] = fmaf(P[i * 4 + 3], 1.0f, v);
+  }
+  const float den = VSL_FADD(o.cam[2], a.eps);
+  const float u = VSL_FDIV(o.cam[0], den), v = VSL_FDIV(o.cam[1], den);
+  o.gx = VSL_FMUL(VSL_FSUB(VSL_FDIV(u, (float)(a.W - 1)), 0.5f), 2.0f);
+  o.gy = VSL_FMUL(VSL_FSUB(VSL_FDIV(v, (float)(a.H - 1)), 0.5f), 2.0f);
+  return o;
+}
+
+__global__ __launch_bounds__(256) void k_warp_fwd(WarpArgs a, float* __restrict__ out, float* __restrict__ sample) {
+  const int b = blockIdx.z, g = blockIdx.y;
+  const int HW = a.H * a.W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  float P[12];
+  load_proj(a.K, a.T, b, P);
+  const WarpPixel w = warp_pixel(a, P, b, p);
+  if (sample && g == 0) {
+    float2v o;
+    o.x = w.gx;
+    o.y = w.gy;
+    *reinterpret_cast<float2v*>(sample + ((size_t)b * HW + p) * 2) = o;
+  }
+  const Taps tx = axis_taps(w.gx, a.W), ty = axis_taps(w.gy, a.H);
+  const int o00 = ty.i0 * a.W + tx.i0, o01 = ty.i0 * a.W + tx.i1, o10 = ty.i1 * a.W + tx.i0, o11 = ty.i1 * a.W + tx.i1;
+  const float w00 = (1.0f - tx.t) * (1.0f - ty.t), w01 = tx.t * (1.0f - ty.t);
+  const float w10 = (1.0f - tx.t) * ty.t, w11 = tx.t * ty.t;
+  const int c1 = min(a.C, (g + 1) * a.cg);
+  for (int c = g * a.cg; c < c1; ++c) {
+    const float* pl = a.feats + ((size_t)b * a.C + c) * HW;
+    out[((size_t)b * a.C + c) * HW + p] = pl[o00] * w00 + pl[o01] * w01 + pl[o10] * w10 + pl[o11] * w11;
+  }
+}
+
+// Backward, first pass: the channel group's share of d L / d (ix, iy) of its pixel into partial[b][g][p] and the
+// scatter of d L / d feats (float atomics; g_feats zeroed by the host).
+__global__ __launch_bounds__(256) void k_warp_bwd_taps(WarpArgs a, const float* __restrict__ g_out, float* __restrict__ g_feats,
+                                                       float* __restrict__ partial) {
+  const int b = blockIdx.z, g = blockIdx.y;
+  const int HW = a.H * a.W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  float P[12];
+  load_proj(a.K, a.T, b, P);
+  const WarpPixel w = warp_pixel(a, P, b, p);
+  const Taps tx = axis_taps(w.gx, a.W), ty = axis_taps(w.gy, a.H);
+  const int o00 = ty.i0 * a.W + tx.i0, o01 = ty.i0 * a.W + tx.i1, o10 = ty.i1 * a.W + tx.i0, o11 = ty.i1 * a.W + tx.i1;
+  const float w00 = (1.0f - tx.t) * (1.0f - ty.t), w01 = tx.t * (1.0f - ty.t);
+  const float w10 = (1.0f - tx.t) * ty.t, w11 = tx.t * ty.t;
+  float gix = 0.0f, giy = 0.0f;
+  const int c1 = min(a.C, (g + 1) * a.cg);
+  for (int c = g * a.cg; c < c1; ++c) {
+    const float go = g_out[((size_t)b * a.C + c) * HW + p];
+    const float* pl = a.feats + ((size_t)b * a.C + c) * HW;
+    const float v00 = pl[o00], v01 = pl[o01], v10 = pl[o10], v11 = pl[o11];
+    gix = fmaf(go, (1.0f - ty.t) * (v01 - v00) + ty.t * (v11 - v10), gix);
+    giy = fmaf(go, (1.0f - tx.t) * (v10 - v00) + tx.t * (v11 - v01), giy);
+    if (g_feats) {
+      float* gp = g_feats + ((size_t)b * a.C + c) * HW;
+      atomicAdd(gp + o00, go * w00);
+      atomicAdd(gp + o01, go * w01);
+      atomicAdd(gp + o10, go * w10);
+      atomicAdd(gp + o11, go * w11);
+    }
+  }
+  float2v o;
+  o.x = gix;
+  o.y = giy;
+  *reinterpret_cast<float2v*>(partial + (((size_t)b * gridDim.y + g) * HW + p) * 2) = o;
+}
+
+// Backward, second pass: sum the groups in fixed order, chain through sampling, projection, back-projection and
+// disp_to_depth to d L / d disp, and reduce d L / d P per block into sums[b][block][12].
+__global__ __launch_bounds__(256) void k_warp_bwd_chain(WarpArgs a, const float* __restrict__ partial, int groups,
+                                                        float* __restrict__ g_disp, float* __restrict__ sums) {
+  __shared__ float red[12][4];
+  const int b = blockIdx.y;
+  const int HW = a.H * a.W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  float P[12];
+  load_proj(a.K, a.T, b, P);
+  float acc[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) acc[e] = 0.0f;
+  if (p < HW) {
+    const WarpPixel w = warp_pixel(a, P, b, p);
+    const Taps tx = axis_taps(w.gx, a.W), ty = axis_taps(w.gy, a.H);
+    float gix = 0.0f, giy = 0.0f;
+    for (int g = 0; g < groups; ++g) {
+      const float2v v = *reinterpret_cast<const float2v*>(partial + (((size_t)b * groups + g) * HW + p) * 2);
+      gix += v.x;
+      giy += v.y;
+    }
+    // d ix / d gx = W/2 (align_corners=False), d gx / d u = 2/(W-1)
+    const float gu = gix * tx.live * ((float)a.W / (float)(a.W - 1)), gv = giy * ty.live * ((float)a.H / (float)(a.H - 1));
+    const float id = 1.0f / (w.cam[2] + a.eps);
+    const float gc[3] = {gu * id, gv * id, -(gu * w.cam[0] + gv * w.cam[1]) * id * id};
+    float g_depth = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float gX = P[0 * 4 + j] * gc[0] + P[1 * 4 + j] * gc[1] + P[2 * 4 + j] * gc[2];
+      g_depth = fmaf(gX, w.ray[j], g_depth);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) acc[i * 4 + j] = gc[i] * w.X[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i * 4 + 3] = gc[i];
+    if (g_disp) g_disp[(size_t)b * HW + p] = -g_depth * a.c_disp / (w.sd * w.sd);
+  }
+#pragma unroll
+  for (int e = 0; e < 12; ++e) {
+    float v = acc[e];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if ((threadIdx.x & 63) == 0) red[e][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const float s = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    sums[((size_t)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = s;
+  }
+}
+
+constexpr int kWarpGroupChannels = 8;
+static_assert(sizeof(vsl_warp_desc) == 72, "vsl_warp_desc layout is part of the ABI");
+
+int warp_groups(int C) { return (C + kWarpGroupChannels - 1) / kWarpGroupChannels; }
+
+int check_warp(const vsl_warp_desc* d) {
+  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "warp descriptor is null");
+  if (int rc = check_hw(d->B, d->H, d->W)) return rc;
+  if (d->H < 2 || d->W < 2) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: need H >= 2 and W >= 2");
+  if (d->C < 1 || d->C > 65535 * kWarpGroupChannels) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: C out of range");
+  if ((long long)d->B * d->C * d->H * d->W >= (1LL << 31)) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: B*C*H*W must be < 2^31");
+  if (!(d->min_depth > 0.0f) || !(d->max_depth > d->min_depth)) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: depth range");
+  if (!d->feats || !d->disp || !d->K || !d->inv_K || !d->T) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: NULL tensor");
+  return VSL_OK;
+}
+
+WarpArgs warp_args(const vsl_warp_desc* d) {
+  WarpArgs a;
+  a.feats = d->feats;
+  a.disp = d->disp;
+  a.K = d->K;
+  a.inv_K = d->inv_K;
+  a.T = d->T;
+  a.C = d->C;
+  a.H = d->H;
+  a.W = d->W;
+  a.cg = kWarpGroupChannels;
+  a.a_disp = (float)(1.0 / (double)d->max_depth);
+  a.c_disp = (float)(1.0 / (double)d->min_depth - 1.0 / (double)d->max_depth);
+  a.eps = d->eps;
+  return a;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t vsl_warp_features_workspace_bytes(const vsl_warp_desc* d) {
+  if (!d || d->B < 1 || d->C < 1 || d->H < 1 || d->W < 1) return 0;
+  const size_t HW = (size_t)d->H * d->W;
+  const size_t blocks = (HW + 255) / 256;
+  return ((size_t)d->B * warp_groups(d->C) * HW * 2 + (size_t)d->B * blocks * 12) * sizeof(float);
+}
+
+int vsl_warp_features_fwd(const vsl_warp_desc* d, float* out, float* sample, void* stream) {
+  if (int rc = check_warp(d)) return rc;
+  if (!out) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: NULL output");
+  const int bx = (d->H * d->W + 255) / 256;
+  hipLaunchKernelGGL(k_warp_fwd, dim3(bx, warp_groups(d->C), d->B), dim3(256), 0, (hipStream_t)stream, warp_args(d), out, sample);
+  return launch_status();
+}
+
+int vsl_warp_features_bwd(const vsl_warp_desc* d, const float* g_out, float* g_feats, float* g_disp, float* g_T,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_warp(d)) return rc;
+  if (!g_out || !workspace) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features backward: NULL tensor");
+  if (workspace_bytes < vsl_warp_features_workspace_bytes(d))
+    return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "warp_features backward: workspace too small");
+  if ((uintptr_t)workspace % 8) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features backward: workspace must be 8-byte aligned");
+  const size_t HW = (size_t)d->H * d->W;
+  const int bx = (int)((HW + 255) / 256), groups = warp_groups(d->C);
+  if (g_feats && hipMemsetAsync(g_feats, 0, (size_t)d->B * d->C * HW * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return fail(VSL_ERR_LAUNCH_FAILED, "warp_features backward: memset failed");
+  float* partial = (float*)workspace;
+  float* sums = partial + (size_t)d->B * groups * HW * 2;
+  const WarpArgs a = warp_args(d);
+  hipLaunchKernelGGL(k_warp_bwd_taps, dim3(bx, groups, d->B), dim3(256), 0, (hipStream_t)stream, a, g_out, g_feats, partial);
+  if (g_disp || g_T) {
+    hipLaunchKernelGGL(k_warp_bwd_chain, dim3(bx, d->B), dim3(256), 0, (hipStream_t)stream, a, (const float*)partial, groups,
+                       g_disp, sums);
+    if (g_T)
+      hipLaunchKernelGGL(k_project_bwd_finish, dim3(d->B), dim3(64), 0, (hipStream_t)stream, (const float*)sums, bx, d->K, d->T,
+                         g_T, (float*)nullptr);
+  }
+  return launch_status();
+}
 
 int vsl_disp_to_depth_fwd(const float* disp, float* scaled, float* depth, long long n, float min_depth, float max_depth,
                           void* stream) {

@@ -16,6 +16,7 @@ reference, take the batch size from the input instead of the constructor.
     transformation_from_parameters(axisangle, translation, invert=False)       layers.py:28
     poses_from_parameters([...], [...], inverts, t_scale)   every source pose of a step in one launch
     mean_inverse_depth(disp, min_depth, max_depth)                             Trainer.py:451-452
+    warp_features(feats, disp, K, inv_K, T)          fused coarse-scale feature warp, Train_distillation_new.py:1159-1182
 """
 from __future__ import annotations
 
@@ -365,6 +366,55 @@ class _MeanInvDepth(torch.autograd.Function):
 def mean_inverse_depth(disp, min_depth, max_depth):
     """Per-image mean of 1/depth, ``(1 / depth).mean(3, True).mean(2, True)`` of Trainer.py:451-452, as [B]."""
     return _MeanInvDepth.apply(disp, min_depth, max_depth)
+
+
+# ------------------------------------------------------------------ feature warping (Train_distillation_new.py:1159-1182)
+class _WarpFeatures(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, disp, K, inv_K, T, min_depth, max_depth, eps):
+        feats, disp = _prep(feats, "feats"), _prep(disp, "disp")
+        K, inv_K, T = _prep(K, "K"), _prep(inv_K, "inv_K"), _prep(T, "T")
+        if feats.dim() != 4 or disp.dim() != 4 or disp.shape[1] != 1 or disp.shape[0] != feats.shape[0] \
+                or disp.shape[2:] != feats.shape[2:]:
+            raise ValueError("feats must be [B,C,H,W] and disp [B,1,H,W] of the same size")
+        B, C, H, W = feats.shape
+        if any(tuple(m.shape) != (B, 4, 4) for m in (K, inv_K, T)):
+            raise ValueError("K, inv_K and T must be [B,4,4]")
+        d = _abi.WarpDesc()
+        d.B, d.C, d.H, d.W = B, C, H, W
+        d.min_depth, d.max_depth, d.eps = float(min_depth), float(max_depth), float(eps)
+        d.feats, d.disp, d.K, d.inv_K, d.T = (t.data_ptr() for t in (feats, disp, K, inv_K, T))
+        out = torch.empty_like(feats)
+        sample = torch.empty(B, H, W, 2, dtype=torch.float32, device=feats.device)
+        _abi.check(_lib.vsl_warp_features_fwd(ctypes.byref(d), out.data_ptr(), sample.data_ptr(), _stream(feats)))
+        ctx.save_for_backward(feats, disp, K, inv_K, T)
+        ctx.desc = d
+        ctx.mark_non_differentiable(sample)
+        return out, sample
+
+    @staticmethod
+    def backward(ctx, g_out, _g_sample):
+        feats, disp, K, inv_K, T = ctx.saved_tensors
+        d = ctx.desc
+        g_out = g_out.float().contiguous()
+        need = ctx.needs_input_grad
+        g_feats = torch.empty_like(feats) if need[0] else None
+        g_disp = torch.empty_like(disp) if need[1] else None
+        g_T = torch.empty_like(T) if need[4] else None
+        nbytes = _lib.vsl_warp_features_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=feats.device)
+        _abi.check(_lib.vsl_warp_features_bwd(ctypes.byref(d), g_out.data_ptr(), _ptr(g_feats), _ptr(g_disp), _ptr(g_T),
+                                              ws.data_ptr(), ws.numel() * 8, _stream(feats)))
+        return g_feats, g_disp, None, None, g_T, None, None, None
+
+
+def warp_features(feats, disp, K, inv_K, T, min_depth=0.1, max_depth=100.0, eps=1e-7, return_sample=False):
+    """``F.grid_sample(feats, Project3D(BackprojectDepth(disp_to_depth(disp)[1], inv_K), K, T), padding_mode="border")``
+    in one pass, as Train_distillation_new.py:1159-1182 builds ``prev_maps[("feats", k)]`` at 24x80, 12x40 and 6x20;
+    ``disp`` is the disparity already interpolated to the size of ``feats``.  Gradients reach ``feats`` (atomic
+    scatter), ``disp`` and ``T``."""
+    out, sample = _WarpFeatures.apply(feats, disp, K, inv_K, T, min_depth, max_depth, eps)
+    return (out, sample) if return_sample else out
 
 
 # ------------------------------------------------------------------ the reference's two helpers, for completeness

@@ -11,6 +11,7 @@ has no GPU, and ``torch.randn`` is pinned to the recorded tie-break noise while
 
     python oracle/make_golden.py               # rewrites tests/golden/*.npz
     python oracle/make_golden.py --pose-only   # only the pose-preparation fixtures
+    python oracle/make_golden.py --warp-only   # only the feature-warping fixtures
 
 Every file holds: the inputs (fp32 values; the reference is fed their float64
 copies, as its data loader would produce), every intermediate the reference
@@ -258,14 +259,48 @@ def run_pose_cases(layers, trainer, out_dir):
     print("pose/pose_params.npz, %s.npz  seed=%d margin=%.2e loss=%.10f" % (c["name"], seed, margin, float(rec["loss"])))
 
 
+def run_feature_warp_cases(layers, out_dir):
+    """Coarse-scale feature warping as Train_distillation_new.py:1159-1182 spells it out (the trainer module itself
+    pulls in networks that are not installed, so the lines are replayed here on the reference's own layers):
+    F.interpolate(disp) -> disp_to_depth -> BackprojectDepth(B,h,w) -> Project3D(B,h,w) -> F.grid_sample(feats, grid,
+    padding_mode="border"), float32 throughout, with the full-resolution K / inv_K at every size."""
+    import torch.nn.functional as F
+    os.makedirs(os.path.join(out_dir, "warp"), exist_ok=True)
+    B, Hf, Wf, C = 2, 24, 80, 20
+    for name, (h, w), sigma, seed in (("feat_12x40", (12, 40), 0.01, 50), ("feat_6x20", (6, 20), 0.01, 51),
+                                      ("feat_24x80", (24, 80), 0.01, 52), ("feat_13x37_large_motion", (13, 37), 0.2, 53)):
+        data = synth.make_batch(B, Hf, Wf, [0, -1], seed=seed, pose_sigma=sigma)
+        feats = torch.from_numpy(synth.normal(seed + 100, (B, C, h, w)).astype(np.float32))
+        feats = F.avg_pool2d(F.pad(feats, (1, 1, 1, 1), mode="replicate"), 3, 1).clone().requires_grad_(True)
+        disp = data[("disp", 0)]
+        disp_k = F.interpolate(disp, [h, w], mode="bilinear", align_corners=False).clone().requires_grad_(True)
+        T = data[("cam_T_cam", -1)].clone().requires_grad_(True)
+        _, depth_k = layers.disp_to_depth(disp_k, 0.1, 100.0)
+        cam = layers.BackprojectDepth(B, h, w)(depth_k, data["inv_K"])
+        pix = layers.Project3D(B, h, w)(cam, data["K"], T)
+        out = F.grid_sample(feats, pix, padding_mode="border")
+        g_out = torch.from_numpy(synth.normal(seed + 200, (B, C, h, w)).astype(np.float32))
+        (out * g_out).sum().backward()
+        np.savez_compressed(os.path.join(out_dir, "warp", name + ".npz"), feats=feats.detach().numpy(),
+                            disp=disp_k.detach().numpy(), K=data["K"].numpy(), inv_K=data["inv_K"].numpy(),
+                            T=T.detach().numpy(), sample=pix.detach().numpy(), out=out.detach().numpy(), g_out=g_out.numpy(),
+                            g_feats=feats.grad.numpy(), g_disp=disp_k.grad.numpy(), g_T=T.grad.numpy())
+        print("warp/%s.npz  |out|=%.6f  out-of-range samples %.1f %%" % (
+            name, float(out.abs().mean()), 100 * float((pix.abs() > 1).any(-1).float().mean())))
+
+
 def main():
     torch.set_num_threads(1)   # deterministic summation order on the CPU
     layers, trainer, distil = load_reference()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    if "--warp-only" in sys.argv:
+        run_feature_warp_cases(layers, out_dir)
+        return
     run_pose_cases(layers, trainer, out_dir)
     if "--pose-only" in sys.argv:
         return
+    run_feature_warp_cases(layers, out_dir)
     for c in CASES:
         path, loss, g = run_case(c, layers, trainer, distil, out_dir)
         print("%-40s loss=%.10f |grad_disp|_1=%.6e  %6.1f KB" % (

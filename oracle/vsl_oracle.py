@@ -148,6 +148,17 @@ def warp(image: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
                          padding_mode="border", align_corners=False)
 
 
+def warp_features(feats: torch.Tensor, disp: torch.Tensor, K: torch.Tensor, inv_K: torch.Tensor, T: torch.Tensor,
+                  min_depth: float = 0.1, max_depth: float = 100.0):
+    """Train_distillation_new.py:1159-1164 (and :1168-1182 at the coarser sizes): disparity already resized to
+    the feature map's size -> depth -> points -> grid -> grid_sample of the float32 features.  Returns
+    (warped features, grid)."""
+    _, depth = disp_to_depth(disp, min_depth, max_depth)
+    h, w = feats.shape[2:]
+    grid = project(backproject(depth, inv_K), K, T, h, w)
+    return warp(feats, grid), grid
+
+
 # --------------------------------------------------------------------------
 # photometric terms
 # --------------------------------------------------------------------------

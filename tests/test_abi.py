@@ -108,3 +108,25 @@ def test_pose_descriptor_validation_without_gpu():
     assert abi.lib.vsl_mean_inv_depth_fwd(fake, fake, fake, 8, 12, 192, 640, 0.1, 100.0, None) == -2
     assert abi.lib.vsl_mean_inv_depth_fwd(fake, fake, fake, 1 << 20, 12, 0, 640, 0.1, 100.0, None) == -1
     assert abi.lib.vsl_mean_inv_depth_bwd(fake, None, fake, 0, 12, 192, 640, 0.1, 100.0, None) == -1
+
+
+def test_warp_descriptor_validation_without_gpu():
+    import mde_amd._abi as abi
+    assert ctypes.sizeof(abi.WarpDesc) == 72
+    fake = 0x1000
+    d = abi.WarpDesc()
+    err = lambda: abi.lib.vsl_last_error_string()
+    assert abi.lib.vsl_warp_features_workspace_bytes(ctypes.byref(d)) == 0
+    d.B, d.C, d.H, d.W = 12, 128, 24, 80
+    d.min_depth, d.max_depth, d.eps = 0.1, 100.0, 1e-7
+    need = abi.lib.vsl_warp_features_workspace_bytes(ctypes.byref(d))
+    assert need == (12 * 16 * 1920 * 2 + 12 * 8 * 12) * 4
+    assert abi.lib.vsl_warp_features_fwd(ctypes.byref(d), fake, None, None) == -1 and b"NULL" in err()
+    d.feats = d.disp = d.K = d.inv_K = d.T = fake
+    assert abi.lib.vsl_warp_features_fwd(ctypes.byref(d), None, None, None) == -1
+    assert abi.lib.vsl_warp_features_bwd(ctypes.byref(d), fake, None, None, None, fake, need - 1, None) == -2
+    assert abi.lib.vsl_warp_features_bwd(ctypes.byref(d), fake, None, None, None, fake + 4, need, None) == -1
+    d.W = 1
+    assert abi.lib.vsl_warp_features_fwd(ctypes.byref(d), fake, None, None) == -1
+    d.W, d.max_depth = 80, 0.05
+    assert abi.lib.vsl_warp_features_fwd(ctypes.byref(d), fake, None, None) == -1 and b"depth" in err()

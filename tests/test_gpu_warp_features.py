@@ -1,0 +1,132 @@
+"""GPU parity of the fused coarse-scale feature warp (vsl_warp_features_fwd/bwd through the C-ABI) against the
+fixtures replayed from the reference's layers (Train_distillation_new.py:1159-1182) and against the module-by-module
+kernels.  Sampling grid bit-exact; warped features and gradients 1e-5 relative (L2); the gradient of the features
+is accumulated with float atomics, so its last bits vary from run to run."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLDEN_DIR
+from oracle import vsl_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+CASES = ["feat_12x40", "feat_6x20", "feat_24x80", "feat_13x37_large_motion"]
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, "warp", name + ".npz"), allow_pickle=False)
+
+
+def leaves(z, dev=DEV):
+    t = {k: torch.from_numpy(z[k]).to(dev) for k in ("feats", "disp", "K", "inv_K", "T", "g_out")}
+    for k in ("feats", "disp", "T"):
+        t[k].requires_grad_(True)
+    return t
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fused_feature_warp_matches_reference_fixture(name):
+    import mde_amd.layers as L
+    z = load(name)
+    t = leaves(z)
+    out, sample = L.warp_features(t["feats"], t["disp"], t["K"], t["inv_K"], t["T"], return_sample=True)
+    flips = int((sample.cpu().numpy() != z["sample"]).sum())
+    assert flips == 0, "%d sampling coordinates differ in their bits" % flips
+    err = rel(out, z["out"])
+    assert err <= TOL, "warped features %.2e" % err
+    (out * t["g_out"]).sum().backward()
+    errs = {k: rel(t[n].grad, z[k]) for n, k in (("feats", "g_feats"), ("disp", "g_disp"), ("T", "g_T"))}
+    if name.endswith("large_motion"):
+        # points next to the camera plane: 1/z^2 amplifies float32 rounding in the reference's own g_disp / g_T;
+        # bounded against a float64 evaluation instead (no further from it than twice the reference is, +1e-5)
+        f64 = {k: torch.from_numpy(z[k]).double() for k in ("feats", "disp", "K", "inv_K", "T")}
+        for k in ("feats", "disp", "T"):
+            f64[k].requires_grad_(True)
+        old, O.FIXED_ORDER = O.FIXED_ORDER, False
+        try:
+            o64, _ = O.warp_features(f64["feats"], f64["disp"], f64["K"], f64["inv_K"], f64["T"])
+        finally:
+            O.FIXED_ORDER = old
+        (o64 * torch.from_numpy(z["g_out"]).double()).sum().backward()
+        for n, k in (("disp", "g_disp"), ("T", "g_T")):
+            e_dev, e_ref = rel(t[n].grad, f64[n].grad), rel(z[k], f64[n].grad)
+            assert e_dev <= 2 * e_ref + TOL, "%s: device %.2e, reference %.2e from float64" % (k, e_dev, e_ref)
+        assert errs["g_feats"] <= TOL, "g_feats %.2e" % errs["g_feats"]
+    else:
+        assert all(e <= TOL for e in errs.values()), str(errs)
+
+
+def test_fused_feature_warp_equals_module_by_module_kernels():
+    """128 channels at 24x80, batch 12 (the size of Train_distillation_new.py:1159-1164): the fused pass against
+    disp_to_depth -> BackprojectDepth -> Project3D -> grid_sample_border on the per-module kernels."""
+    import mde_amd.layers as L
+    import mde_amd.synth as synth
+    B, C, H, W = 12, 128, 24, 80
+    data = synth.make_batch(B, H, W, [0, -1], seed=61)
+    g = torch.Generator().manual_seed(5)
+    feats0 = torch.randn(B, C, H, W, generator=g)
+    g_out = torch.randn(B, C, H, W, generator=g).to(DEV)
+    res = {}
+    for mode in ("fused", "modules"):
+        feats = feats0.to(DEV).requires_grad_(True)
+        disp = data[("disp", 0)].to(DEV).requires_grad_(True)
+        T = data[("cam_T_cam", -1)].to(DEV).requires_grad_(True)
+        K, inv_K = data["K"].to(DEV), data["inv_K"].to(DEV)
+        if mode == "fused":
+            out, sample = L.warp_features(feats, disp, K, inv_K, T, return_sample=True)
+        else:
+            _, depth = L.disp_to_depth(disp, 0.1, 100.0)
+            sample = L.Project3D(B, H, W)(L.BackprojectDepth(B, H, W)(depth, inv_K), K, T)
+            out = L.grid_sample_border(feats, sample)
+        (out * g_out).sum().backward()
+        res[mode] = (sample.detach(), out.detach(), feats.grad, disp.grad, T.grad)
+    assert torch.equal(res["fused"][0], res["modules"][0])
+    assert torch.equal(res["fused"][1], res["modules"][1])
+    for i, what in ((2, "g_feats"), (3, "g_disp"), (4, "g_T")):
+        err = rel(res["fused"][i], res["modules"][i])
+        assert err <= TOL, "%s %.2e" % (what, err)
+
+
+def test_odd_channel_count_and_no_gradient_for_constants():
+    import mde_amd.layers as L
+    z = load("feat_12x40")
+    t = leaves(z)
+    feats = t["feats"][:, :13].detach().contiguous().requires_grad_(True)      # 13 channels: a partial channel group
+    out = L.warp_features(feats, t["disp"].detach(), t["K"], t["inv_K"], t["T"].detach())
+    err = rel(out, z["out"][:, :13])
+    assert err <= TOL, "%.2e" % err
+    (out * t["g_out"][:, :13]).sum().backward()
+    ref = torch.from_numpy(z["feats"][:, :13]).clone().requires_grad_(True)
+    o, _ = O.warp_features(ref, torch.from_numpy(z["disp"]), torch.from_numpy(z["K"]), torch.from_numpy(z["inv_K"]),
+                           torch.from_numpy(z["T"]))
+    (o * torch.from_numpy(z["g_out"][:, :13])).sum().backward()
+    err = rel(feats.grad, ref.grad)
+    assert err <= TOL, "%.2e" % err
+
+
+def test_warp_argument_errors():
+    import mde_amd._abi as abi
+    import mde_amd.layers as L
+    f = torch.zeros(2, 4, 6, 8, device=DEV)
+    d = torch.zeros(2, 1, 6, 8, device=DEV)
+    M = torch.eye(4, device=DEV).repeat(2, 1, 1)
+    with pytest.raises(ValueError):
+        L.warp_features(f, torch.zeros(2, 1, 5, 8, device=DEV), M, M, M)
+    with pytest.raises(ValueError):
+        L.warp_features(f, d, M[:1], M, M)
+    with pytest.raises(ValueError):
+        L.warp_features(f.cpu(), d.cpu(), M.cpu(), M.cpu(), M.cpu())
+    desc = abi.WarpDesc()
+    desc.B, desc.C, desc.H, desc.W = 2, 4, 1, 8
+    assert abi.lib.vsl_warp_features_fwd(ctypes.byref(desc), None, None, None) == -1

@@ -128,3 +128,20 @@ def test_posecnn_mode_matches_reference_fixture():
     for f in fids[1:]:
         assert close(params[f][0].grad.numpy(), z["g_axisangle_%s" % f])
         assert close(params[f][1].grad.numpy(), z["g_translation_%s" % f])
+
+
+@pytest.mark.parametrize("name", ["feat_12x40", "feat_6x20", "feat_24x80", "feat_13x37_large_motion"])
+def test_feature_warp_matches_reference_fixture(name):
+    """Coarse-scale feature warping (Train_distillation_new.py:1159-1182) replayed on the reference's layers:
+    grid bit-identical, warped features and gradients to float32 rounding."""
+    z = np.load(os.path.join(GOLDEN_DIR, "warp", name + ".npz"))
+    feats = torch.from_numpy(z["feats"]).clone().requires_grad_(True)
+    disp = torch.from_numpy(z["disp"]).clone().requires_grad_(True)
+    T = torch.from_numpy(z["T"]).clone().requires_grad_(True)
+    out, grid = O.warp_features(feats, disp, torch.from_numpy(z["K"]), torch.from_numpy(z["inv_K"]), T)
+    np.testing.assert_array_equal(grid.detach().numpy(), z["sample"])
+    np.testing.assert_allclose(out.detach().numpy(), z["out"], rtol=0, atol=1e-6)
+    (out * torch.from_numpy(z["g_out"])).sum().backward()
+    for got, key in ((feats.grad, "g_feats"), (disp.grad, "g_disp"), (T.grad, "g_T")):
+        err = np.linalg.norm(got.numpy() - z[key]) / np.linalg.norm(z[key])
+        assert err <= 1e-5, "%s %.2e" % (key, err)
