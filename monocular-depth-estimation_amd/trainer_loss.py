@@ -28,13 +28,16 @@ import torch.nn.functional as F
 
 from . import _abi
 from .layers import (BackprojectDepth, Project3D, SSIM, disp_to_depth, get_smooth_loss, grid_sample_border,
-                     mean_inverse_depth, poses_from_parameters)
+                     mean_inverse_depth, poses_from_parameters, warp_features)
 from .ops import fused_view_synthesis_loss, fused_view_synthesis_loss_heads
 
 
 class ViewSynthesisLoss:
-    def __init__(self, opt, num_scales: int = 1, photometric_scale: float = 1.0, seed: int = 0):
+    def __init__(self, opt, num_scales: int = 1, photometric_scale: float = 1.0, seed: int = 0,
+                 use_affinity: bool = False):
         self.opt = opt
+        self.use_affinity = use_affinity      # Trainer.py:26
+        self.val_mode = False                 # Trainer.py:25: the affinity term is skipped while validating
         self.num_scales = num_scales          # the reference fixes this to 1 (Trainer.py:33)
         self.photometric_scale = photometric_scale
         self.seed = seed
@@ -104,6 +107,8 @@ class ViewSynthesisLoss:
             grid = self.project_3d(points, inputs["K"], T)
             outputs[("sample", f)] = grid
             outputs[("color", f)] = grid_sample_border(inputs[("image", f)], grid)
+            if self.use_affinity and not self.val_mode:                      # Trainer.py:468-473
+                outputs[("pred_affinity", f)] = grid_sample_border(inputs[("affinity", f)][:, 0], grid)
             if not self.opt.disable_automasking:
                 outputs[("color_identity", f)] = inputs[("image", f)]
 
@@ -116,18 +121,43 @@ class ViewSynthesisLoss:
             return l1
         return 0.85 * self.ssim(pred, target).mean(1, True) + 0.15 * l1
 
+    # ------------------------------------------------------------------ Trainer.py:497-516
+    def compute_affinity_reprojection_loss(self, input_, t_seg, target, weight, rand: Optional[torch.Tensor] = None):
+        """Squared error between the warped affinity map and the target frame's, the target multiplied by the
+        prediction where ``rand < weight[1]``; ``t_seg`` does not enter the value (Trainer.py:508-514).  Six
+        elementwise torch ops on the device; the 25-channel gather before it is the HIP part."""
+        target = target.float().to(input_.device)
+        rand = torch.rand_like(target) if rand is None else rand.to(input_.device)
+        keep = (rand < weight[1]).float()
+        drop = torch.where(keep == 1.0, input_, torch.ones_like(target))
+        return torch.mean((input_ - target * drop) ** 2)
+
+    def _affinity_term(self, inputs, outputs, disp, poses, drop_rand):
+        """Sum over the sources of the affinity loss (Trainer.py:546-548), each map warped by the fused
+        disp -> depth -> backproject -> project -> sample pass so that the gradient reaches disp and the poses."""
+        total = 0
+        for f, T in zip(self._sources(), poses):
+            pred = warp_features(inputs[("affinity", f)][:, 0], disp, inputs["K"], inputs["inv_K"], T,
+                                 self.opt.min_depth, self.opt.max_depth)
+            outputs[("pred_affinity", f)] = pred
+            total = total + self.compute_affinity_reprojection_loss(pred, inputs.get(("segmentation", 0)),
+                                                                    inputs[("affinity", 0)][:, 0], [1.5, 0.5], drop_rand)
+        return total
+
     # ------------------------------------------------------------------ Trainer.py:518-620
     def compute_losses(self, inputs: Dict, outputs: Dict, noise: Optional[torch.Tensor] = None,
-                       photometric_scale: Optional[float] = None) -> Dict[str, torch.Tensor]:
+                       photometric_scale: Optional[float] = None,
+                       drop_rand: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         opt = self.opt
         srcs = self._sources()
         disp = self._full_res_disp(outputs)
         automask = not opt.disable_automasking
         scale_w = [opt.disparity_smoothness / (2 ** s) for s in opt.scales]
         self._step += 1
+        poses = self._poses(inputs, outputs, disp)
         out, ident = fused_view_synthesis_loss(
             disp, inputs[("image", 0)], [inputs[("image", f)] for f in srcs], inputs["K"], inputs["inv_K"],
-            self._poses(inputs, outputs, disp), noise,
+            poses, noise,
             automask=automask, avg_reprojection=opt.avg_reprojection, no_ssim=opt.no_ssim,
             scale_weights=scale_w, inv_num_scales=1.0 / self.num_scales,
             warp_scale=self.photometric_scale if photometric_scale is None else photometric_scale,
@@ -136,6 +166,11 @@ class ViewSynthesisLoss:
             outputs["identity_selection"] = ident
         losses = {"loss/{}".format(s): out[_abi.LOSS_SCALE0 + i] for i, s in enumerate(opt.scales)}
         losses["loss"] = out[_abi.LOSS_TOTAL]
+        if self.use_affinity and not self.val_mode:
+            # Trainer.py:606: the same affinity term is added to every scale's loss
+            aff = self._affinity_term(inputs, outputs, disp, poses, drop_rand)
+            losses = {k: v + aff for k, v in losses.items() if k != "loss"}
+            losses["loss"] = out[_abi.LOSS_TOTAL] + aff * (len(opt.scales) / self.num_scales)
         return losses
 
     def compute_losses_per_scale(self, inputs: Dict, outputs: Dict, noise: Optional[torch.Tensor] = None,

@@ -12,6 +12,7 @@ has no GPU, and ``torch.randn`` is pinned to the recorded tie-break noise while
     python oracle/make_golden.py               # rewrites tests/golden/*.npz
     python oracle/make_golden.py --pose-only   # only the pose-preparation fixtures
     python oracle/make_golden.py --warp-only   # only the feature-warping fixtures
+    python oracle/make_golden.py --affinity-only
 
 Every file holds: the inputs (fp32 values; the reference is fed their float64
 copies, as its data loader would produce), every intermediate the reference
@@ -259,6 +260,60 @@ def run_pose_cases(layers, trainer, out_dir):
     print("pose/pose_params.npz, %s.npz  seed=%d margin=%.2e loss=%.10f" % (c["name"], seed, margin, float(rec["loss"])))
 
 
+def run_affinity_case(layers, trainer, out_dir):
+    """Trainer.generate_images_pred + compute_losses with use_affinity=True (Trainer.py:468-473,497-516,546-548,606):
+    a 25-channel map per frame warped with the colour grid, squared error against the target frame's map with the
+    random drop-out of :502-506 (torch.rand_like pinned to a recorded tensor)."""
+    c = dict(name="b2_24x80_affinity", B=2, H=24, W=80, frame_ids=[0, -1, 1], automask=True, seed=70,
+             avg_reprojection=False, no_ssim=False, scales=[0, 1])
+    B, H, W, fids = c["B"], c["H"], c["W"], c["frame_ids"]
+    data = synth.make_batch(B, H, W, fids, seed=c["seed"])
+    noise = data["noise"].contiguous()
+    tr = make_trainer(trainer.Trainer, layers, B, H, W, c)
+    tr.use_affinity = True
+    inputs = {"K": data["K"], "inv_K": data["inv_K"]}
+    rec = {}
+    for j, f in enumerate(fids):
+        inputs[("image", f)] = data[("image", f)].double()
+        a = torch.from_numpy(synth.uniform(80 + j, (B, 1, 25, H, W)).astype(np.float32))
+        a = torch.nn.functional.avg_pool3d(torch.nn.functional.pad(a, (1, 1, 1, 1, 0, 0), mode="replicate"), (1, 3, 3), 1)
+        inputs[("affinity", f)] = a.contiguous()
+        rec["affinity_%s" % f] = inputs[("affinity", f)].numpy()
+    inputs[("segmentation", 0)] = (torch.from_numpy(synth.uniform(90, (B, 4, H, W)).astype(np.float32)) > 0.5).float()
+    rec["segmentation"] = inputs[("segmentation", 0)].numpy()
+    drop_rand = torch.from_numpy(synth.uniform(91, (B, 25, H, W)).astype(np.float32))
+    disp = data[("disp", 0)].clone().requires_grad_(True)
+    outputs = {("disp", 0): disp}
+    poses = {}
+    for f in fids[1:]:
+        poses[f] = data[("cam_T_cam", f)].clone().requires_grad_(True)
+        outputs[("cam_T_cam", f)] = poses[f]
+    real_randn, real_rand_like = torch.randn, torch.rand_like
+    torch.randn = lambda *a, **k: noise.clone()
+    torch.rand_like = lambda t, **k: drop_rand.clone().to(t.dtype)
+    try:
+        tr.generate_images_pred(inputs, outputs)
+        losses = tr.compute_losses(inputs, outputs)
+    finally:
+        torch.randn, torch.rand_like = real_randn, real_rand_like
+    losses["loss"].backward()
+    rec.update({"config": np.array(json.dumps(c)), "disp": data[("disp", 0)].numpy(), "K": data["K"].numpy(),
+                "inv_K": data["inv_K"].numpy(), "noise": noise.numpy(), "drop_rand": drop_rand.numpy(),
+                "loss": losses["loss"].detach().numpy(), "grad_disp": disp.grad.numpy(),
+                "identity_selection": outputs["identity_selection"].numpy()})
+    for s_ in c["scales"]:
+        rec["loss_%d" % s_] = losses["loss/%d" % s_].detach().numpy()
+    for f in fids:
+        rec["image_%s" % f] = data[("image", f)].numpy()
+    for f in fids[1:]:
+        rec["T_%s" % f] = poses[f].detach().numpy()
+        rec["grad_T_%s" % f] = poses[f].grad.numpy()
+        rec["pred_affinity_%s" % f] = outputs[("pred_affinity", f)].detach().numpy().astype(np.float32)
+    os.makedirs(os.path.join(out_dir, "affinity"), exist_ok=True)
+    np.savez_compressed(os.path.join(out_dir, "affinity", c["name"] + ".npz"), **rec)
+    print("affinity/%s.npz  loss=%.10f" % (c["name"], float(rec["loss"])))
+
+
 def run_feature_warp_cases(layers, out_dir):
     """Coarse-scale feature warping as Train_distillation_new.py:1159-1182 spells it out (the trainer module itself
     pulls in networks that are not installed, so the lines are replayed here on the reference's own layers):
@@ -294,6 +349,9 @@ def main():
     layers, trainer, distil = load_reference()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    if "--affinity-only" in sys.argv:
+        run_affinity_case(layers, trainer, out_dir)
+        return
     if "--warp-only" in sys.argv:
         run_feature_warp_cases(layers, out_dir)
         return
@@ -301,6 +359,7 @@ def main():
     if "--pose-only" in sys.argv:
         return
     run_feature_warp_cases(layers, out_dir)
+    run_affinity_case(layers, trainer, out_dir)
     for c in CASES:
         path, loss, g = run_case(c, layers, trainer, distil, out_dir)
         print("%-40s loss=%.10f |grad_disp|_1=%.6e  %6.1f KB" % (

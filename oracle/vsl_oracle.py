@@ -58,6 +58,7 @@ class LossConfig:
     warp_scale: float = 1.0             # 0.9 in Trainer_distilation.compute_losses
     num_scales: int = 1                 # Trainer.py:33 (divisor of the total)
     pose_model_type: str = "shared"     # "posecnn": T rebuilt from the parameters x mean inverse depth
+    use_affinity: bool = False          # Trainer.py:26 (and not val_mode): affinity warp + loss
 
     @property
     def sources(self) -> List:
@@ -220,16 +221,30 @@ def view_synthesis(inputs: Dict, outputs: Dict, cfg: LossConfig) -> None:
             grid = project(pts, inputs["K"], T, cfg.height, cfg.width)
             outputs[("sample", f)] = grid
             outputs[("color", f)] = warp(inputs[("image", f)], grid)
+            if cfg.use_affinity:                                     # Trainer.py:468-473
+                outputs[("pred_affinity", f)] = warp(inputs[("affinity", f)][:, 0].double(), grid)
             if cfg.automask:
                 outputs[("color_identity", f)] = inputs[("image", f)]
 
 
+def affinity_reprojection_loss(pred: torch.Tensor, target: torch.Tensor, weight: Sequence[float],
+                               rand: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Trainer.py:497-516 -- squared error between the warped affinity map and the target frame's map, the target
+    multiplied by the prediction itself where ``rand < weight[1]`` (the segmentation sums of :508-510 do not enter
+    the value).  ``rand`` is the U[0,1) tensor of :502, drawn with torch.rand_like when omitted."""
+    rand = torch.rand_like(target) if rand is None else rand
+    keep = (rand < weight[1]).float()
+    drop = torch.where(keep == 1.0, pred, torch.ones_like(target))
+    return torch.mean((pred - target * drop) ** 2)
+
+
 def compute_losses(inputs: Dict, outputs: Dict, cfg: LossConfig,
-                   noise: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-    """Trainer.py:518-620 (affinity / predictive-mask branches excluded).
+                   noise: Optional[torch.Tensor] = None, drop_rand: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """Trainer.py:518-620 (predictive-mask branch excluded).
 
     ``noise`` is the N(0,1) tie-break tensor of Trainer.py:589 ([B,S,H,W], or
     [B,1,H,W] with avg_reprojection); drawn from torch.randn when omitted.
+    ``drop_rand`` pins the uniform tensor of the affinity term (Trainer.py:502).
     """
     losses: Dict[str, torch.Tensor] = {}
     total = 0
@@ -263,6 +278,10 @@ def compute_losses(inputs: Dict, outputs: Dict, cfg: LossConfig,
             outputs["identity_selection"] = (idx > ident.shape[1] - 1).float()
 
         loss = chosen.mean()
+        if cfg.use_affinity:                                         # Trainer.py:546-548,606
+            for f in cfg.sources:
+                loss = loss + affinity_reprojection_loss(outputs[("pred_affinity", f)], inputs[("affinity", 0)][:, 0],
+                                                         [1.5, 0.5], drop_rand)
         mean_disp = disp.mean(2, True).mean(3, True)
         loss = loss + cfg.disparity_smoothness * smoothness(disp / (mean_disp + 1e-7), target) / (2 ** scale)
         total = total + loss
@@ -272,10 +291,10 @@ def compute_losses(inputs: Dict, outputs: Dict, cfg: LossConfig,
 
 
 def loss_forward_backward(inputs: Dict, outputs: Dict, cfg: LossConfig,
-                          noise: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                          noise: Optional[torch.Tensor] = None, drop_rand: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """One pass of the whole path: view synthesis, losses, backward."""
     view_synthesis(inputs, outputs, cfg)
-    losses = compute_losses(inputs, outputs, cfg, noise)
+    losses = compute_losses(inputs, outputs, cfg, noise, drop_rand)
     losses["loss"].backward()
     return losses
 

@@ -130,3 +130,49 @@ def test_warp_argument_errors():
     desc = abi.WarpDesc()
     desc.B, desc.C, desc.H, desc.W = 2, 4, 1, 8
     assert abi.lib.vsl_warp_features_fwd(ctypes.byref(desc), None, None, None) == -1
+
+
+def test_affinity_term_matches_reference_fixture():
+    """ViewSynthesisLoss(use_affinity=True).compute_losses against the reference's Trainer with use_affinity=True
+    (Trainer.py:468-473,497-516,546-548,606): warped 25-channel maps, loss per scale, gradients of disparity and poses."""
+    import json
+    import types
+    from mde_amd.trainer_loss import ViewSynthesisLoss
+    z = np.load(os.path.join(GOLDEN_DIR, "affinity", "b2_24x80_affinity.npz"), allow_pickle=False)
+    c = json.loads(str(z["config"]))
+    fids = c["frame_ids"]
+    opt = types.SimpleNamespace(scales=c["scales"], frame_ids=fids, height=c["H"], width=c["W"], min_depth=0.1,
+                                max_depth=100.0, v1_multiscale=False, disable_automasking=False, avg_reprojection=False,
+                                no_ssim=False, disparity_smoothness=1e-3)
+    vs = ViewSynthesisLoss(opt, use_affinity=True)
+    inputs = {"K": torch.from_numpy(z["K"]).to(DEV), "inv_K": torch.from_numpy(z["inv_K"]).to(DEV),
+              ("segmentation", 0): torch.from_numpy(z["segmentation"]).to(DEV)}
+    for f in fids:
+        inputs[("image", f)] = torch.from_numpy(z["image_%s" % f]).to(DEV)
+        inputs[("affinity", f)] = torch.from_numpy(z["affinity_%s" % f]).to(DEV)
+    disp = torch.from_numpy(z["disp"]).to(DEV).requires_grad_(True)
+    outputs = {("disp", 0): disp}
+    poses = {}
+    for f in fids[1:]:
+        poses[f] = torch.from_numpy(z["T_%s" % f]).to(DEV).requires_grad_(True)
+        outputs[("cam_T_cam", f)] = poses[f]
+    losses = vs.compute_losses(inputs, outputs, noise=torch.from_numpy(z["noise"]).to(DEV),
+                               drop_rand=torch.from_numpy(z["drop_rand"]).to(DEV))
+    losses["loss"].backward()
+    assert abs(losses["loss"].item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    for s_ in c["scales"]:
+        assert abs(losses["loss/%d" % s_].item() - float(z["loss_%d" % s_])) <= TOL * abs(float(z["loss_%d" % s_]))
+    flips = int((outputs["identity_selection"].cpu().numpy() != z["identity_selection"]).sum())
+    assert flips == 0
+    for f in fids[1:]:
+        e = rel(outputs[("pred_affinity", f)], z["pred_affinity_%s" % f])
+        assert e <= TOL, "pred_affinity %s %.2e" % (f, e)
+        e = rel(poses[f].grad, z["grad_T_%s" % f])
+        assert e <= TOL, "grad_T %s %.2e" % (f, e)
+    e = rel(disp.grad, z["grad_disp"])
+    assert e <= TOL, "grad_disp %.2e" % e
+    # validation mode skips the term (Trainer.py:468,546)
+    vs.val_mode = True
+    plain = vs.compute_losses(inputs, {("disp", 0): disp.detach(), **{("cam_T_cam", f): poses[f].detach() for f in fids[1:]}},
+                              noise=torch.from_numpy(z["noise"]).to(DEV))
+    assert plain["loss"].item() < losses["loss"].item()

@@ -145,3 +145,32 @@ def test_feature_warp_matches_reference_fixture(name):
     for got, key in ((feats.grad, "g_feats"), (disp.grad, "g_disp"), (T.grad, "g_T")):
         err = np.linalg.norm(got.numpy() - z[key]) / np.linalg.norm(z[key])
         assert err <= 1e-5, "%s %.2e" % (key, err)
+
+
+def test_affinity_term_matches_reference_fixture():
+    """Trainer.py:468-473,497-516,546-548,606 with use_affinity=True: the warped 25-channel maps, the loss per scale
+    and the gradients of disparity and poses."""
+    z = np.load(os.path.join(GOLDEN_DIR, "affinity", "b2_24x80_affinity.npz"))
+    c = json.loads(str(z["config"]))
+    fids = c["frame_ids"]
+    cfg = O.LossConfig(frame_ids=fids, scales=c["scales"], height=c["H"], width=c["W"], automask=True, use_affinity=True)
+    inputs = {"K": torch.from_numpy(z["K"]), "inv_K": torch.from_numpy(z["inv_K"])}
+    for f in fids:
+        inputs[("image", f)] = torch.from_numpy(z["image_%s" % f]).double()
+        inputs[("affinity", f)] = torch.from_numpy(z["affinity_%s" % f])
+    disp = torch.from_numpy(z["disp"]).clone().requires_grad_(True)
+    outputs = {("disp", 0): disp}
+    poses = {}
+    for f in fids[1:]:
+        poses[f] = torch.from_numpy(z["T_%s" % f]).clone().requires_grad_(True)
+        outputs[("cam_T_cam", f)] = poses[f]
+    losses = O.loss_forward_backward(inputs, outputs, cfg, torch.from_numpy(z["noise"]), torch.from_numpy(z["drop_rand"]))
+    assert abs(losses["loss"].item() - float(z["loss"])) <= 1e-7 * abs(float(z["loss"]))
+    for s_ in c["scales"]:
+        assert abs(losses["loss/%d" % s_].item() - float(z["loss_%d" % s_])) <= 1e-7 * abs(float(z["loss_%d" % s_]))
+    for f in fids[1:]:
+        np.testing.assert_allclose(outputs[("pred_affinity", f)].detach().numpy(), z["pred_affinity_%s" % f], rtol=0, atol=1e-6)
+        err = np.linalg.norm(poses[f].grad.numpy() - z["grad_T_%s" % f]) / np.linalg.norm(z["grad_T_%s" % f])
+        assert err <= 1e-5, "grad_T %s %.2e" % (f, err)
+    err = np.linalg.norm(disp.grad.numpy() - z["grad_disp"]) / np.linalg.norm(z["grad_disp"])
+    assert err <= 1e-5, "grad_disp %.2e" % err
