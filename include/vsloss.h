@@ -274,6 +274,43 @@ int vsl_warp_features_fwd(const vsl_warp_desc* desc, float* out, float* sample, 
 int vsl_warp_features_bwd(const vsl_warp_desc* desc, const float* g_out, float* g_feats, float* g_disp, float* g_T,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Depth metrics of a step, Trainer.compute_depth_losses (Python/Trainer.py:622-662) with compute_depth_errors
+ * (Python/layers.py:265-283): the predicted depth is resized to the ground truth's size (bilinear,
+ * align_corners=False) and clamped, the mask is depth_gt > 0 inside crop rows [y0,y1) x columns [x0,x1)
+ * (Python slice semantics; the reference hard-codes 375 x 1242 and the Garg/Eigen crop 153:371, 44:1197), the
+ * prediction is scaled by median(gt) / median(pred) over the whole batch (lower middle element, as torch.median)
+ * and clamped again, then the seven means.  No host synchronisation, deterministic.
+ */
+#define VSL_METRIC_ABS_REL 0
+#define VSL_METRIC_SQ_REL 1
+#define VSL_METRIC_RMSE 2
+#define VSL_METRIC_RMSE_LOG 3
+#define VSL_METRIC_A1 4
+#define VSL_METRIC_A2 5
+#define VSL_METRIC_A3 6
+#define VSL_METRIC_SUM 7        /* depth_errors of Trainer.py:659: the sum of the seven                    */
+#define VSL_METRIC_COUNT 8      /* number of masked pixels (as float)                                      */
+#define VSL_METRIC_MEDIAN_GT 9
+#define VSL_METRIC_MEDIAN_PRED 10
+#define VSL_METRIC_SLOTS 11
+
+typedef struct vsl_depth_metrics_desc {
+  int32_t B, H, W;                 /* predicted depth [B,1,H,W], outputs[("depth",0)]              */
+  int32_t Hg, Wg;                  /* ground truth [B,1,Hg,Wg], inputs["depth_gt"]                 */
+  int32_t crop_y0, crop_y1, crop_x0, crop_x1;
+  float clamp_min, clamp_max;      /* 1e-3, 80 (Trainer.py:628-629,648)                            */
+  uint32_t reserved;
+  const float* depth;
+  const float* depth_gt;
+} vsl_depth_metrics_desc;
+
+size_t vsl_depth_metrics_workspace_bytes(const vsl_depth_metrics_desc* desc);
+/* metrics: out [VSL_METRIC_SLOTS] device floats (NaN means for an empty mask, where the reference raises);
+ * workspace: vsl_depth_metrics_workspace_bytes(desc) bytes, 256-byte aligned. */
+int vsl_depth_metrics(const vsl_depth_metrics_desc* desc, float* metrics, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 /* Library version, e.g. 100 for 0.1.0. */
 int vsl_version(void);
 

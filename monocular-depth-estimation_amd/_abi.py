@@ -26,7 +26,7 @@ EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", 
            "vsl_project_fwd", "vsl_project_bwd_workspace_bytes", "vsl_project_bwd",
            "vsl_grid_sample_fwd", "vsl_grid_sample_bwd", "vsl_ssim_fwd", "vsl_ssim_bwd",
            "vsl_smooth_workspace_bytes", "vsl_smooth_fwd", "vsl_smooth_bwd",
-           "vsl_pose_fwd", "vsl_pose_bwd",
+           "vsl_pose_fwd", "vsl_pose_bwd", "vsl_depth_metrics_workspace_bytes", "vsl_depth_metrics",
            "vsl_warp_features_workspace_bytes", "vsl_warp_features_fwd", "vsl_warp_features_bwd",
            "vsl_mean_inv_depth_workspace_bytes", "vsl_mean_inv_depth_fwd", "vsl_mean_inv_depth_bwd",
            "vsl_debug_fused_occupancy", "vsl_debug_time_fused", "vsl_last_error_string", "vsl_version")
@@ -74,6 +74,20 @@ class WarpDesc(ctypes.Structure):
         ("min_depth", ctypes.c_float), ("max_depth", ctypes.c_float), ("eps", ctypes.c_float), ("reserved", ctypes.c_uint32),
         ("feats", ctypes.c_void_p), ("disp", ctypes.c_void_p), ("K", ctypes.c_void_p), ("inv_K", ctypes.c_void_p),
         ("T", ctypes.c_void_p),
+    ]
+
+
+METRIC_NAMES = ("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3")
+METRIC_SUM, METRIC_COUNT, METRIC_MEDIAN_GT, METRIC_MEDIAN_PRED, METRIC_SLOTS = 7, 8, 9, 10, 11
+
+
+class DepthMetricsDesc(ctypes.Structure):
+    """Mirror of ``vsl_depth_metrics_desc`` (include/vsloss.h)."""
+    _fields_ = [
+        ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("Hg", ctypes.c_int32), ("Wg", ctypes.c_int32),
+        ("crop_y0", ctypes.c_int32), ("crop_y1", ctypes.c_int32), ("crop_x0", ctypes.c_int32), ("crop_x1", ctypes.c_int32),
+        ("clamp_min", ctypes.c_float), ("clamp_max", ctypes.c_float), ("reserved", ctypes.c_uint32),
+        ("depth", ctypes.c_void_p), ("depth_gt", ctypes.c_void_p),
     ]
 
 
@@ -140,6 +154,10 @@ def _load():
     lib.vsl_warp_features_fwd.argtypes = [ctypes.POINTER(WarpDesc), P, P, P]
     lib.vsl_warp_features_bwd.restype = ctypes.c_int
     lib.vsl_warp_features_bwd.argtypes = [ctypes.POINTER(WarpDesc), P, P, P, P, P, SZ, P]
+    lib.vsl_depth_metrics_workspace_bytes.restype = ctypes.c_size_t
+    lib.vsl_depth_metrics_workspace_bytes.argtypes = [ctypes.POINTER(DepthMetricsDesc)]
+    lib.vsl_depth_metrics.restype = ctypes.c_int
+    lib.vsl_depth_metrics.argtypes = [ctypes.POINTER(DepthMetricsDesc), P, P, SZ, P]
     lib.vsl_mean_inv_depth_workspace_bytes.restype = ctypes.c_size_t
     lib.vsl_mean_inv_depth_workspace_bytes.argtypes = [I]
     lib.vsl_mean_inv_depth_fwd.restype = ctypes.c_int

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvsloss.so")
-SOURCES = ["vsl_loss.hip", "vsl_layers.hip", "vsl_pose.hip"]
+SOURCES = ["vsl_loss.hip", "vsl_layers.hip", "vsl_pose.hip", "vsl_metrics.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

@@ -17,6 +17,7 @@ reference, take the batch size from the input instead of the constructor.
     poses_from_parameters([...], [...], inverts, t_scale)   every source pose of a step in one launch
     mean_inverse_depth(disp, min_depth, max_depth)                             Trainer.py:451-452
     warp_features(feats, disp, K, inv_K, T)          fused coarse-scale feature warp, Train_distillation_new.py:1159-1182
+    depth_metrics(depth, depth_gt)                   Trainer.compute_depth_losses + compute_depth_errors, Trainer.py:622-662
 """
 from __future__ import annotations
 
@@ -415,6 +416,29 @@ def warp_features(feats, disp, K, inv_K, T, min_depth=0.1, max_depth=100.0, eps=
     scatter), ``disp`` and ``T``."""
     out, sample = _WarpFeatures.apply(feats, disp, K, inv_K, T, min_depth, max_depth, eps)
     return (out, sample) if return_sample else out
+
+
+# ------------------------------------------------------------------ depth metrics (Trainer.py:622-662, layers.py:265-283)
+def depth_metrics(depth, depth_gt, crop=(153, 371, 44, 1197), clamp=(1e-3, 80.0)):
+    """The masked, median-scaled depth metrics of ``Trainer.compute_depth_losses`` in one stream-ordered call
+    (no gather, no sort, no host synchronisation).  Returns a float32 tensor of ``_abi.METRIC_SLOTS`` values:
+    abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, their sum, the masked count and the two medians.  Carries no
+    gradient: the reference detaches the prediction (Trainer.py:630)."""
+    depth, depth_gt = _prep(depth.detach(), "depth"), _prep(depth_gt, "depth_gt")
+    if depth.dim() != 4 or depth.shape[1] != 1 or depth_gt.dim() != 4 or depth_gt.shape[1] != 1 \
+            or depth_gt.shape[0] != depth.shape[0]:
+        raise ValueError("depth must be [B,1,H,W] and depth_gt [B,1,Hg,Wg]")
+    d = _abi.DepthMetricsDesc()
+    d.B, d.H, d.W = depth.shape[0], depth.shape[2], depth.shape[3]
+    d.Hg, d.Wg = depth_gt.shape[2], depth_gt.shape[3]
+    d.crop_y0, d.crop_y1, d.crop_x0, d.crop_x1 = (int(v) for v in crop)
+    d.clamp_min, d.clamp_max = float(clamp[0]), float(clamp[1])
+    d.depth, d.depth_gt = depth.data_ptr(), depth_gt.data_ptr()
+    nbytes = _lib.vsl_depth_metrics_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=depth.device)
+    out = torch.empty(_abi.METRIC_SLOTS, dtype=torch.float32, device=depth.device)
+    _abi.check(_lib.vsl_depth_metrics(ctypes.byref(d), out.data_ptr(), ws.data_ptr(), nbytes, _stream(depth)))
+    return out
 
 
 # ------------------------------------------------------------------ the reference's two helpers, for completeness

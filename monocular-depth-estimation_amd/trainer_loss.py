@@ -18,6 +18,7 @@ fields read are: scales, frame_ids, height, width, min_depth, max_depth, v1_mult
 disable_automasking, avg_reprojection, no_ssim, disparity_smoothness, pose_model_type.
 
     pose_outputs(axisangle, translation) -> {("cam_T_cam",f), ...}   Trainer.py:388-393,408-414
+    compute_depth_losses(inputs, outputs, losses) -> (sum, [7 metrics])   Trainer.py:622-662
 """
 from __future__ import annotations
 
@@ -27,8 +28,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _abi
-from .layers import (BackprojectDepth, Project3D, SSIM, disp_to_depth, get_smooth_loss, grid_sample_border,
-                     mean_inverse_depth, poses_from_parameters, warp_features)
+from .layers import (BackprojectDepth, Project3D, SSIM, depth_metrics, disp_to_depth, get_smooth_loss,
+                     grid_sample_border, mean_inverse_depth, poses_from_parameters, warp_features)
 from .ops import fused_view_synthesis_loss, fused_view_synthesis_loss_heads
 
 
@@ -172,6 +173,17 @@ class ViewSynthesisLoss:
             losses = {k: v + aff for k, v in losses.items() if k != "loss"}
             losses["loss"] = out[_abi.LOSS_TOTAL] + aff * (len(opt.scales) / self.num_scales)
         return losses
+
+    # ------------------------------------------------------------------ Trainer.py:622-662
+    def compute_depth_losses(self, inputs: Dict, outputs: Dict, losses: Optional[Dict] = None):
+        """(sum of the seven metrics, [abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3]) as 0-dim device tensors, from
+        outputs[("depth",0)] (or, when the fused loss ran without materialising it, from the disparity) and
+        inputs["depth_gt"]; the target size is depth_gt's (375 x 1242 in the reference), the crop is the reference's."""
+        depth = outputs.get(("depth", 0))
+        if depth is None:
+            _, depth = disp_to_depth(self._full_res_disp(outputs).detach(), self.opt.min_depth, self.opt.max_depth)
+        m = depth_metrics(depth, inputs["depth_gt"])
+        return m[_abi.METRIC_SUM], [m[i] for i in range(7)]
 
     def compute_losses_per_scale(self, inputs: Dict, outputs: Dict, noise: Optional[torch.Tensor] = None,
                                  photometric_scale: Optional[float] = None) -> Dict[str, torch.Tensor]:

@@ -13,6 +13,7 @@ has no GPU, and ``torch.randn`` is pinned to the recorded tie-break noise while
     python oracle/make_golden.py --pose-only   # only the pose-preparation fixtures
     python oracle/make_golden.py --warp-only   # only the feature-warping fixtures
     python oracle/make_golden.py --affinity-only
+    python oracle/make_golden.py --metrics-only
 
 Every file holds: the inputs (fp32 values; the reference is fed their float64
 copies, as its data loader would produce), every intermediate the reference
@@ -314,6 +315,33 @@ def run_affinity_case(layers, trainer, out_dir):
     print("affinity/%s.npz  loss=%.10f" % (c["name"], float(rec["loss"])))
 
 
+def run_depth_metric_cases(layers, trainer, out_dir):
+    """Trainer.compute_depth_losses (Trainer.py:622-662) on a predicted depth and a sparse 375 x 1242 ground truth
+    (LiDAR-like: a few percent of the pixels carry a value)."""
+    os.makedirs(os.path.join(out_dir, "metrics"), exist_ok=True)
+    for name, B, H, W, density, seed in (("b2_48x160", 2, 48, 160, 0.05, 110), ("b3_24x80_even_count", 3, 24, 80, 0.02, 111)):
+        tr = object.__new__(trainer.Trainer)
+        disp = synth.make_batch(B, H, W, [0], seed=seed)[("disp", 0)]
+        _, depth = layers.disp_to_depth(disp, 0.1, 100.0)
+        gt = 1.0 + 60.0 * torch.from_numpy(synth.uniform(seed + 1, (B, 1, 375, 1242)).astype(np.float32)) ** 2
+        keep = torch.from_numpy(synth.uniform(seed + 2, (B, 1, 375, 1242)).astype(np.float32)) < density
+        gt = gt * keep
+        if name.endswith("even_count"):   # make the masked count even: torch.median then takes the lower middle element
+            m = (gt > 0)
+            m[:, :, :153] = False
+            m[:, :, 371:] = False
+            m[:, :, :, :44] = False
+            m[:, :, :, 1197:] = False
+            if int(m.sum()) % 2 == 1:
+                idx = m.nonzero()[0]
+                gt[tuple(idx)] = 0.0
+        total, metrics = tr.compute_depth_losses({"depth_gt": gt.clone()}, {("depth", 0): depth.clone()}, {})
+        gmask = (gt > 0)
+        np.savez_compressed(os.path.join(out_dir, "metrics", name + ".npz"), depth=depth.numpy(), depth_gt=gt.numpy(),
+                            metrics=np.array([float(v) for v in metrics], np.float64), total=float(total))
+        print("metrics/%s.npz  %s" % (name, " ".join("%.6f" % float(v) for v in metrics)))
+
+
 def run_feature_warp_cases(layers, out_dir):
     """Coarse-scale feature warping as Train_distillation_new.py:1159-1182 spells it out (the trainer module itself
     pulls in networks that are not installed, so the lines are replayed here on the reference's own layers):
@@ -352,6 +380,9 @@ def main():
     if "--affinity-only" in sys.argv:
         run_affinity_case(layers, trainer, out_dir)
         return
+    if "--metrics-only" in sys.argv:
+        run_depth_metric_cases(layers, trainer, out_dir)
+        return
     if "--warp-only" in sys.argv:
         run_feature_warp_cases(layers, out_dir)
         return
@@ -360,6 +391,7 @@ def main():
         return
     run_feature_warp_cases(layers, out_dir)
     run_affinity_case(layers, trainer, out_dir)
+    run_depth_metric_cases(layers, trainer, out_dir)
     for c in CASES:
         path, loss, g = run_case(c, layers, trainer, distil, out_dir)
         print("%-40s loss=%.10f |grad_disp|_1=%.6e  %6.1f KB" % (

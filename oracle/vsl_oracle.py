@@ -335,3 +335,34 @@ def transformation_from_parameters(axisangle: torch.Tensor, translation: torch.T
     Tm = torch.eye(4, dtype=t.dtype, device=t.device).repeat(t.shape[0], 1, 1)
     Tm[:, :3, 3] = t.reshape(-1, 3)
     return torch.matmul(R, Tm) if invert else torch.matmul(Tm, R)
+
+
+# --------------------------------------------------------------------------
+# depth metrics (Trainer.py:622-662, layers.py:265-283)
+# --------------------------------------------------------------------------
+def depth_errors(gt: torch.Tensor, pred: torch.Tensor):
+    """layers.py:265-283 -- (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3) of two 1-D tensors."""
+    thresh = torch.max(gt / pred, pred / gt)
+    a1 = (thresh < 1.25).float().mean()
+    a2 = (thresh < 1.25 ** 2).float().mean()
+    a3 = (thresh < 1.25 ** 3).float().mean()
+    rmse = torch.sqrt(((gt - pred) ** 2).mean())
+    rmse_log = torch.sqrt(((torch.log(gt) - torch.log(pred)) ** 2).mean())
+    abs_rel = torch.mean(torch.abs(gt - pred) / gt)
+    sq_rel = torch.mean((gt - pred) ** 2 / gt)
+    return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
+
+
+def depth_losses(depth: torch.Tensor, depth_gt: torch.Tensor, crop=(153, 371, 44, 1197)):
+    """Trainer.py:622-662 -- depth [B,1,H,W] resized to depth_gt's size (375 x 1242 in the reference), clamped,
+    masked by gt > 0 inside the crop, median-scaled over the batch, clamped; returns (sum of the metrics, metrics)."""
+    pred = torch.clamp(F.interpolate(depth, list(depth_gt.shape[2:]), mode="bilinear", align_corners=False), 1e-3, 80).detach()
+    mask = depth_gt > 0
+    crop_mask = torch.zeros_like(mask)
+    crop_mask[:, :, crop[0]:crop[1], crop[2]:crop[3]] = 1
+    mask = mask * crop_mask
+    gt, pred = depth_gt[mask], pred[mask]
+    pred = pred * (torch.median(gt) / torch.median(pred))
+    pred = torch.clamp(pred, min=1e-3, max=80)
+    m = depth_errors(gt, pred)
+    return sum(m), list(m)

@@ -130,3 +130,23 @@ def test_warp_descriptor_validation_without_gpu():
     assert abi.lib.vsl_warp_features_fwd(ctypes.byref(d), fake, None, None) == -1
     d.W, d.max_depth = 80, 0.05
     assert abi.lib.vsl_warp_features_fwd(ctypes.byref(d), fake, None, None) == -1 and b"depth" in err()
+
+
+def test_depth_metrics_descriptor_validation_without_gpu():
+    import mde_amd._abi as abi
+    assert ctypes.sizeof(abi.DepthMetricsDesc) == 64
+    fake = 0x1000
+    d = abi.DepthMetricsDesc()
+    err = lambda: abi.lib.vsl_last_error_string()
+    assert abi.lib.vsl_depth_metrics_workspace_bytes(ctypes.byref(d)) == 0
+    d.B, d.H, d.W, d.Hg, d.Wg = 12, 192, 640, 375, 1242
+    d.crop_y0, d.crop_y1, d.crop_x0, d.crop_x1 = 153, 371, 44, 1197
+    need = abi.lib.vsl_depth_metrics_workspace_bytes(ctypes.byref(d))
+    assert need >= 12 * 218 * 1153 * 4 and need % 256 == 0
+    assert abi.lib.vsl_depth_metrics(ctypes.byref(d), fake, fake * 16, need, None) == -1 and b"clamp" in err()
+    d.clamp_min, d.clamp_max = 1e-3, 80.0
+    assert abi.lib.vsl_depth_metrics(ctypes.byref(d), fake, fake * 16, need, None) == -1 and b"NULL" in err()
+    d.depth = d.depth_gt = fake
+    assert abi.lib.vsl_depth_metrics(ctypes.byref(d), fake, fake * 16, need - 1, None) == -2
+    assert abi.lib.vsl_depth_metrics(ctypes.byref(d), fake, fake * 16 + 8, need, None) == -1 and b"aligned" in err()
+    assert abi.lib.vsl_depth_metrics(ctypes.byref(d), None, fake * 16, need, None) == -1

@@ -174,3 +174,12 @@ def test_affinity_term_matches_reference_fixture():
         assert err <= 1e-5, "grad_T %s %.2e" % (f, err)
     err = np.linalg.norm(disp.grad.numpy() - z["grad_disp"]) / np.linalg.norm(z["grad_disp"])
     assert err <= 1e-5, "grad_disp %.2e" % err
+
+
+@pytest.mark.parametrize("name", ["b2_48x160", "b3_24x80_even_count"])
+def test_depth_metrics_match_reference_fixture(name):
+    """Trainer.compute_depth_losses (Trainer.py:622-662): same torch ops, so the seven metrics agree to rounding."""
+    z = np.load(os.path.join(GOLDEN_DIR, "metrics", name + ".npz"))
+    total, metrics = O.depth_losses(torch.from_numpy(z["depth"]), torch.from_numpy(z["depth_gt"]))
+    np.testing.assert_allclose(np.array([float(v) for v in metrics]), z["metrics"], rtol=1e-6)
+    assert abs(float(total) - float(z["total"])) <= 1e-6 * abs(float(z["total"]))
