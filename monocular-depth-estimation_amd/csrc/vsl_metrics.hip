@@ -29,7 +29,8 @@ static_assert(sizeof(vsl_depth_metrics_desc) == 64, "vsl_depth_metrics_desc layo
 
 constexpr int kBins = 2048;       // 11 + 11 + 10 bits
 constexpr int kThreads = 256;
-constexpr int kMaxBlocksX = 256;  // pixel blocks per image
+constexpr int kTargetBlocks = 512;  // blocks per launch: every block flushes its histogram with global atomics on the
+                                    // same few dozen addresses, so more blocks cost more than they gain
 
 struct SelectState {
   unsigned hist[2][kBins];  // [0] ground truth, [1] prediction
@@ -102,23 +103,45 @@ __global__ __launch_bounds__(kThreads) void k_hist(MetricArgs a) {
     if (v) atomicAdd(&a.st->hist[0][0] + i, v);
   }
   if (PASS == 0) {
+    __shared__ unsigned cnt[kThreads / 64];
     for (int m = 32; m >= 1; m >>= 1) count += __shfl_xor(count, m, 64);
-    if ((threadIdx.x & 63) == 0 && count) atomicAdd(&a.st->n, count);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0;
+      for (int w = 0; w < kThreads / 64; ++w) t += cnt[w];
+      if (t) atomicAdd(&a.st->n, t);
+    }
   }
 }
 
-// one block: locate the bin that holds the median of each array, extend the prefix, clear the histograms
+// one block of two waves, one per array: locate the bin that holds the median, extend the prefix, clear the
+// histograms.  Every lane sums 32 consecutive bins, a wave scan finds the lane whose range crosses the rank and
+// that lane walks its 32 bins.
 template <int PASS>
 __global__ __launch_bounds__(128) void k_scan(SelectState* st) {
-  const int which = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    unsigned rank = PASS ? st->rank[which] : (st->n ? (st->n - 1u) / 2u : 0u);  // torch.median: the lower middle element
-    unsigned bin = 0, acc = 0;
-    const int bins = PASS == 2 ? 1024 : kBins;
-    for (int i = 0; i < bins; ++i) {
-      const unsigned c = st->hist[which][i];
+  __shared__ unsigned h[2][kBins];
+  for (int i = threadIdx.x; i < 2 * kBins; i += 128) (&h[0][0])[i] = (&st->hist[0][0])[i];
+  __syncthreads();
+  const int which = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned n = st->n;
+  const unsigned rank = PASS ? st->rank[which] : (n ? (n - 1u) / 2u : 0u);  // torch.median: the lower middle element
+  constexpr int PER = kBins / 64;
+  unsigned mine = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) mine += h[which][lane * PER + i];
+  unsigned incl = mine;  // inclusive scan over the lanes
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  const unsigned before = incl - mine;
+  if (before <= rank && rank < incl) {  // exactly one lane when n > 0
+    unsigned acc = before, bin = (unsigned)(lane * PER);
+    for (int i = 0; i < PER; ++i) {
+      const unsigned c = h[which][lane * PER + i];
       if (acc + c > rank) {
-        bin = (unsigned)i;
+        bin = (unsigned)(lane * PER + i);
         break;
       }
       acc += c;
@@ -126,9 +149,9 @@ __global__ __launch_bounds__(128) void k_scan(SelectState* st) {
     st->rank[which] = rank - acc;
     const unsigned prefix = PASS == 0 ? bin : PASS == 1 ? (st->prefix[which] << 11) | bin : (st->prefix[which] << 10) | bin;
     st->prefix[which] = prefix;
-    if (PASS == 2) st->median[which] = st->n ? __uint_as_float(prefix) : __uint_as_float(0x7FC00000u);
+    if (PASS == 2) st->median[which] = __uint_as_float(prefix);
   }
-  __syncthreads();
+  if (PASS == 2 && n == 0 && lane == 0) st->median[which] = __uint_as_float(0x7FC00000u);
   if (PASS < 2)
     for (int i = threadIdx.x; i < 2 * kBins; i += 128) (&st->hist[0][0])[i] = 0u;
 }
@@ -171,13 +194,26 @@ __global__ __launch_bounds__(kThreads) void k_terms(MetricArgs a) {
 }
 
 // metrics[0..6] = abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3; [7] = their sum (Trainer.py:659); [8] = masked count;
-// [9], [10] = the two medians
-__global__ void k_metrics_final(const double* __restrict__ partial, int nblocks, const SelectState* st, float* __restrict__ out) {
+// [9], [10] = the two medians.  One block of 256 threads: strided sums of the block partials, then an LDS tree.
+__global__ __launch_bounds__(256) void k_metrics_final(const double* __restrict__ partial, int nblocks, const SelectState* st,
+                                                       float* __restrict__ out) {
+  __shared__ double red[7][256];
   __shared__ float m[7];
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nblocks; i += 256)
+#pragma unroll
+    for (int e = 0; e < 7; ++e) acc[e] += partial[(size_t)i * 7 + e];
+#pragma unroll
+  for (int e = 0; e < 7; ++e) red[e][threadIdx.x] = acc[e];
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o)
+#pragma unroll
+      for (int e = 0; e < 7; ++e) red[e][threadIdx.x] += red[e][threadIdx.x + o];
+    __syncthreads();
+  }
   if (threadIdx.x < 7) {
-    double s = 0.0;
-    for (int i = 0; i < nblocks; ++i) s += partial[(size_t)i * 7 + threadIdx.x];
-    const double mean = s / (double)st->n;  // 0 / 0 = NaN for an empty mask, where the reference raises
+    const double mean = red[threadIdx.x][0] / (double)st->n;  // 0 / 0 = NaN for an empty mask, where the reference raises
     const float v = (threadIdx.x == 2 || threadIdx.x == 3) ? sqrtf((float)mean) : (float)mean;
     m[threadIdx.x] = v;
     out[threadIdx.x] = v;
@@ -208,7 +244,8 @@ Geometry geometry(const vsl_depth_metrics_desc* d) {
   g.cw = g.x1 > g.x0 ? g.x1 - g.x0 : 0;
   const long long n = (long long)g.ch * g.cw;
   long long bx = (n + kThreads - 1) / kThreads;
-  g.bx = (int)(bx < 1 ? 1 : (bx > kMaxBlocksX ? kMaxBlocksX : bx));
+  const long long cap = kTargetBlocks / d->B > 1 ? kTargetBlocks / d->B : 1;
+  g.bx = (int)(bx < 1 ? 1 : (bx > cap ? cap : bx));
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   g.pred_bytes = up((size_t)d->B * (size_t)n * sizeof(float));
   g.state_off = g.pred_bytes;
@@ -272,7 +309,7 @@ int vsl_depth_metrics(const vsl_depth_metrics_desc* d, float* metrics, void* wor
   hipLaunchKernelGGL(k_hist<2>, grid, dim3(kThreads), 0, s, a);
   hipLaunchKernelGGL(k_scan<2>, dim3(1), dim3(128), 0, s, a.st);
   hipLaunchKernelGGL(k_terms, grid, dim3(kThreads), 0, s, a);
-  hipLaunchKernelGGL(k_metrics_final, dim3(1), dim3(64), 0, s, (const double*)a.partial, g.bx * d->B, (const SelectState*)a.st,
+  hipLaunchKernelGGL(k_metrics_final, dim3(1), dim3(256), 0, s, (const double*)a.partial, g.bx * d->B, (const SelectState*)a.st,
                      metrics);
   return launch_status();
 }
