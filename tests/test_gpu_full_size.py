@@ -260,3 +260,50 @@ def test_student_and_forward_only_teacher_in_one_launch():
                                            warp_scale=0.9)
     # (a launch without any gradient runs the forward-only program: same per-pixel values, other summation order)
     assert torch.allclose(l1, losses[1], rtol=2e-6, atol=0) and torch.equal(i1, ident[1])
+
+
+def test_batch_offsets_just_below_the_index_limit():
+    """B*3*H*W = 2 146 959 360, 524 288 below the documented 2^31 limit (39 images of 8960x2048): the first, a
+    middle and the last image evaluated on their own give the same identity_selection bit for bit and, up to the
+    1/B of the batch mean, the same disparity and pose gradients as inside the batch.  About 55 GB of device memory."""
+    from mde_amd.ops import fused_view_synthesis_loss
+    B, H, W = 39, 2048, 8960
+    assert B * 3 * H * W < 2 ** 31 and (B + 1) * 3 * H * W >= 2 ** 31
+    if torch.cuda.get_device_properties(0).total_memory < 120 * 2 ** 30:
+        pytest.skip("needs a device with more than 120 GB")
+    g = torch.Generator(device=DEV).manual_seed(17)
+    pool = torch.nn.AvgPool2d(5, 1, 2, count_include_pad=False)
+    imgs = [pool(torch.rand(B, 3, H, W, device=DEV, generator=g)) for _ in range(3)]
+    disp = 0.05 + 0.9 * pool(torch.rand(B, 1, H, W, device=DEV, generator=g))
+    noise = torch.randn(B, 2, H, W, device=DEV, generator=g)
+    K = torch.tensor([[0.58 * (W // 2), 0, 0.5 * (W // 2), 0], [0, 1.92 * (H // 2), 0.5 * (H // 2), 0], [0, 0, 1, 0], [0, 0, 0, 1]],
+                     device=DEV).repeat(B, 1, 1)
+    inv_K = torch.linalg.pinv(K)
+    T = [torch.eye(4, device=DEV).repeat(B, 1, 1) for _ in range(2)]
+    for s, t in enumerate(T):
+        t[:, :3, 3] = 0.02 * torch.randn(B, 3, device=DEV, generator=g)
+        t[:, 0, 1] = 0.003 * (s + 1)
+        t[:, 1, 0] = -0.003 * (s + 1)
+
+    def run(sl):
+        d = disp[sl].clone().requires_grad_(True)
+        poses = [t[sl].clone().requires_grad_(True) for t in T]
+        losses, ident = fused_view_synthesis_loss(d, imgs[0][sl], [imgs[1][sl], imgs[2][sl]], K[sl], inv_K[sl], poses, noise[sl])
+        losses[0].backward()
+        return losses.detach(), ident, d.grad, [p.grad for p in poses]
+
+    l_all, sel_all, g_all, gT_all = run(slice(0, B))
+    assert torch.isfinite(l_all[:4]).all() and 0.0 < float(sel_all.mean()) < 1.0
+    for b in (0, B // 2, B - 1):
+        l_one, sel_one, g_one, gT_one = run(slice(b, b + 1))
+        assert torch.equal(sel_one[0], sel_all[b]), "identity_selection of image %d" % b
+        err = float((g_all[b] * B - g_one[0]).norm() / g_one[0].norm())
+        assert err <= TOL, "grad_disp of image %d: %.2e" % (b, err)     # the batch-mean factors round differently
+        for s in range(2):
+            err = float((gT_all[s][b] * B - gT_one[s][0]).norm() / gT_one[s][0].norm())
+            assert err <= 1e-5, "grad_T[%d] of image %d: %.2e" % (s, b, err)
+        del l_one, sel_one, g_one, gT_one
+    # one image more is refused, not mis-indexed
+    with pytest.raises(Exception):
+        big = torch.empty(B + 1, 1, H, W, device=DEV)
+        fused_view_synthesis_loss(big, imgs[0], [imgs[1], imgs[2]], K, inv_K, T, None)
