@@ -76,16 +76,30 @@ def main():
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
+    ap.add_argument("--verbose", action="store_true", help="print a line per stage and step (every rank)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses GPU 0 (rehearsal of the N > 1 path on one card)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", 0 if args.share_gpu else local)
     torch.cuda.set_device(dev)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(args.backend)
 
+    def say(msg):
+        if args.verbose:
+            print("[rank %d] %s" % (rank, msg), flush=True)
+
+    if args.verbose:      # a rank that makes no progress for 45 s prints the Python stack of every thread
+        import faulthandler
+        faulthandler.dump_traceback_later(45, repeat=False)
+    say("process group ready")
     import mde_amd.synth as synth
     from mde_amd.trainer_step import TrainStep
 
@@ -98,7 +112,8 @@ def main():
               "pose": TinyPoseDecoder(len(opt.frame_ids)).to(dev)}
     params = [p for m in models.values() for p in m.parameters()]
     if world > 1:
-        models = {k: nn.parallel.DistributedDataParallel(m, device_ids=[local]) for k, m in models.items()}
+        models = {k: nn.parallel.DistributedDataParallel(m, device_ids=[dev.index]) for k, m in models.items()}
+    say("models wrapped")
     step = TrainStep(opt, models, torch.optim.Adam(params, opt.learning_rate))
 
     data = synth.make_batch(args.batch, args.height, args.width, opt.frame_ids, seed=100 + rank)
@@ -115,6 +130,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         _, losses = step.train_step(inputs)
+        say("step %d done" % i)
         if i == 0:
             first = losses["loss"].item()
     last = losses["loss"].item()
