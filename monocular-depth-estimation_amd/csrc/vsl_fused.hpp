@@ -654,10 +654,12 @@ struct Fused {
     }
     float win[2] = {-1.0f, -1.0f};
     float rsum[2] = {0.0f, 0.0f};
-    if (!AVG) {
+    // (!AVG) the winner's nine coefficients of both pixels stay in registers and go to LDS once, as pairs
+    float wc[2][9];
 #pragma unroll
-      for (int e = 0; e < 9; ++e) *reinterpret_cast<float2v*>(coef + e * P1 + q1) = float2v{0.0f, 0.0f};
-    }
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) wc[k][j] = 0.0f;
     // target-side window sums once per channel
     float sy[3][2], syy[3][2];
     if (!NOSSIM) {
@@ -704,13 +706,18 @@ struct Fused {
           rsum[k] += e;
 #pragma unroll
           for (int j = 0; j < 9; ++j) coef[(s * 9 + j) * P1 + q1 + k] = valid[k] ? cf[k][j] : 0.0f;
-        } else if (valid[k] && e < best[k]) {
-          best[k] = e;
-          win[k] = (float)s;
+        } else {
+          const bool take = valid[k] && e < best[k];
+          best[k] = take ? e : best[k];
+          win[k] = take ? (float)s : win[k];
 #pragma unroll
-          for (int j = 0; j < 9; ++j) coef[j * P1 + q1 + k] = cf[k][j];
+          for (int j = 0; j < 9; ++j) wc[k][j] = take ? cf[k][j] : wc[k][j];
         }
       }
+    }
+    if (!AVG) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) *reinterpret_cast<float2v*>(coef + j * P1 + q1) = float2v{wc[0][j], wc[1][j]};
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
