@@ -144,7 +144,16 @@ VSL_DEV float fast_rcp(float x) {
 #endif
 }
 
-VSL_DEV float sgn(float v) { return (float)(v > 0.0f) - (float)(v < 0.0f); }
+// sign(v) in {-1, 0, 1}.  On the device: two exact scalings by 2^126 take every non-zero finite value (denormals
+// included) beyond 1 in magnitude, the median with -1 and 1 clamps it: three instructions instead of two
+// compares, two selects and a subtraction; same values.
+VSL_DEV float sgn(float v) {
+#if defined(__HIPCC__)
+  return __builtin_amdgcn_fmed3f(v * 0x1p126f * 0x1p126f, -1.0f, 1.0f);
+#else
+  return (float)(v > 0.0f) - (float)(v < 0.0f);
+#endif
+}
 
 // splitmix64-style hash -> N(0,1); used when the caller passes no noise tensor
 VSL_DEV float hash_normal(unsigned long long seed, unsigned long long idx) {
@@ -350,6 +359,51 @@ VSL_DEV void ssim_pair(const float xw[3][4], const float yw[3][4], const float s
     c1[j] = (e0 + e1) + e2;
     c2[j] = fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
     c3[j] = fmaf(e2, d2, fmaf(e1, d1, e0 * d0));
+  }
+  float sx[2], sxx[2], sxy[2];
+  two_windows(c1, sx);
+  two_windows(c2, sxx);
+  two_windows(c3, sxy);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) out[k] = ssim_formula(cx, cy, sx[k], sxx[k], sxy[k], sy[k], syy[k], want_coef);
+}
+
+// The same two steps with the target-side differences d = y - y_centre formed once and shared between the
+// target statistics and every source frame (same values, same operation order per result).
+VSL_DEV void y_diffs(const float yw[3][4], float d[3][4]) {
+  const float cy = yw[1][1];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[r][j] = yw[r][j] - cy;
+}
+VSL_DEV void y_stats_d(const float d[3][4], float sy[2], float syy[2]) {
+  float c1[4], c2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c1[j] = (d[0][j] + d[1][j]) + d[2][j];
+    c2[j] = fmaf(d[2][j], d[2][j], fmaf(d[1][j], d[1][j], d[0][j] * d[0][j]));
+  }
+  float s1[2], s2[2];
+  two_windows(c1, s1);
+  two_windows(c2, s2);
+  constexpr float i9 = 1.0f / 9.0f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    sy[k] = s1[k] * i9;
+    syy[k] = fmaf(s2[k], i9, -sy[k] * sy[k]) + kC2;
+  }
+}
+VSL_DEV void ssim_pair_d(const float xw[3][4], float cy, const float d[3][4], const float sy[2], const float syy[2],
+                         bool want_coef, SsimOut out[2]) {
+  const float cx = xw[1][1];
+  float c1[4], c2[4], c3[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float e0 = xw[0][j] - cx, e1 = xw[1][j] - cx, e2 = xw[2][j] - cx;
+    c1[j] = (e0 + e1) + e2;
+    c2[j] = fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
+    c3[j] = fmaf(e2, d[2][j], fmaf(e1, d[1][j], e0 * d[0][j]));
   }
   float sx[2], sxx[2], sxy[2];
   two_windows(c1, sx);
@@ -660,64 +714,129 @@ struct Fused {
     for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int j = 0; j < 9; ++j) wc[k][j] = 0.0f;
-    // target-side window sums once per channel
-    float sy[3][2], syy[3][2];
-    if (!NOSSIM) {
+    if constexpr (S <= 3) {
+      // Channel by channel: the target window, its differences to the centre and its statistics are formed once and
+      // serve every source frame; the per-source sums over the channels keep their order (c ascending).
+      float fsum[S][2], lsum[S][2];
+      float cf[S][2][9];
+#pragma unroll
+      for (int s = 0; s < S; ++s) fsum[s][0] = fsum[s][1] = lsum[s][0] = lsum[s][1] = 0.0f;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        float yw[3][4];
+        float yw[3][4], dy[3][4], sy[2], syy[2];
         load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
-        y_stats(yw, sy[c], syy[c]);
-        VSL_SCHED_FENCE();
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      float fsum[2] = {0.0f, 0.0f}, lsum[2] = {0.0f, 0.0f};
-      float cf[2][9];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float yw[3][4], xw[3][4];
-        load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
-        load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
-        lsum[0] += fabsf(yw[1][1] - xw[1][1]);
-        lsum[1] += fabsf(yw[1][2] - xw[1][2]);
         if (!NOSSIM) {
-          SsimOut o[2];
-          ssim_pair(xw, yw, sy[c], syy[c], hv.want_grad != 0, o);
+          y_diffs(yw, dy);
+          y_stats_d(dy, sy, syy);
+        }
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            fsum[k] += o[k].f;
-            cf[k][c * 3 + 0] = o[k].A;
-            cf[k][c * 3 + 1] = o[k].B;
-            cf[k][c * 3 + 2] = o[k].G;
+        for (int s = 0; s < S; ++s) {
+          float xw[3][4];
+          load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
+          lsum[s][0] += fabsf(yw[1][1] - xw[1][1]);
+          lsum[s][1] += fabsf(yw[1][2] - xw[1][2]);
+          if (!NOSSIM) {
+            SsimOut o[2];
+            ssim_pair_d(xw, yw[1][1], dy, sy, syy, hv.want_grad != 0, o);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              fsum[s][k] += o[k].f;
+              cf[s][k][c * 3 + 0] = o[k].A;
+              cf[s][k][c * 3 + 1] = o[k].B;
+              cf[s][k][c * 3 + 2] = o[k].G;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) cf[s][k][c * 3 + 0] = cf[s][k][c * 3 + 1] = cf[s][k][c * 3 + 2] = 0.0f;
           }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 2; ++k) cf[k][c * 3 + 0] = cf[k][c * 3 + 1] = cf[k][c * 3 + 2] = 0.0f;
         }
         VSL_SCHED_FENCE();
       }
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        float e = NOSSIM ? lsum[k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[k], kp.l1_w3 * lsum[k]);
-        e *= kp.warp_scale;
-        if (AVG) {
-          rsum[k] += e;
+      for (int s = 0; s < S; ++s) {
 #pragma unroll
-          for (int j = 0; j < 9; ++j) coef[(s * 9 + j) * P1 + q1 + k] = valid[k] ? cf[k][j] : 0.0f;
-        } else {
-          const bool take = valid[k] && e < best[k];
-          best[k] = take ? e : best[k];
-          win[k] = take ? (float)s : win[k];
+        for (int k = 0; k < 2; ++k) {
+          float e = NOSSIM ? lsum[s][k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[s][k], kp.l1_w3 * lsum[s][k]);
+          e *= kp.warp_scale;
+          if (AVG) {
+            rsum[k] += e;
 #pragma unroll
-          for (int j = 0; j < 9; ++j) wc[k][j] = take ? cf[k][j] : wc[k][j];
+            for (int j = 0; j < 9; ++j) coef[(s * 9 + j) * P1 + q1 + k] = valid[k] ? cf[s][k][j] : 0.0f;
+          } else {
+            const bool take = valid[k] && e < best[k];
+            best[k] = take ? e : best[k];
+            win[k] = take ? (float)s : win[k];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) wc[k][j] = take ? cf[s][k][j] : wc[k][j];
+          }
         }
       }
-    }
-    if (!AVG) {
+      if (!AVG) {
 #pragma unroll
-      for (int j = 0; j < 9; ++j) *reinterpret_cast<float2v*>(coef + j * P1 + q1) = float2v{wc[0][j], wc[1][j]};
+        for (int j = 0; j < 9; ++j) *reinterpret_cast<float2v*>(coef + j * P1 + q1) = float2v{wc[0][j], wc[1][j]};
+      }
+    } else {
+      // four sources: the per-source coefficient sets of the channel-outer order no longer fit the register budget
+      // of three workgroups per CU, so the sources are walked one after the other
+      // target-side window sums once per channel
+      float sy[3][2], syy[3][2];
+      if (!NOSSIM) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float yw[3][4];
+          load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
+          y_stats(yw, sy[c], syy[c]);
+          VSL_SCHED_FENCE();
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float fsum[2] = {0.0f, 0.0f}, lsum[2] = {0.0f, 0.0f};
+        float cf[2][9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float yw[3][4], xw[3][4];
+          load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
+          load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
+          lsum[0] += fabsf(yw[1][1] - xw[1][1]);
+          lsum[1] += fabsf(yw[1][2] - xw[1][2]);
+          if (!NOSSIM) {
+            SsimOut o[2];
+            ssim_pair(xw, yw, sy[c], syy[c], hv.want_grad != 0, o);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              fsum[k] += o[k].f;
+              cf[k][c * 3 + 0] = o[k].A;
+              cf[k][c * 3 + 1] = o[k].B;
+              cf[k][c * 3 + 2] = o[k].G;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) cf[k][c * 3 + 0] = cf[k][c * 3 + 1] = cf[k][c * 3 + 2] = 0.0f;
+          }
+          VSL_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          float e = NOSSIM ? lsum[k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[k], kp.l1_w3 * lsum[k]);
+          e *= kp.warp_scale;
+          if (AVG) {
+            rsum[k] += e;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) coef[(s * 9 + j) * P1 + q1 + k] = valid[k] ? cf[k][j] : 0.0f;
+          } else {
+            const bool take = valid[k] && e < best[k];
+            best[k] = take ? e : best[k];
+            win[k] = take ? (float)s : win[k];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) wc[k][j] = take ? cf[k][j] : wc[k][j];
+          }
+        }
+      }
+      if (!AVG) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) *reinterpret_cast<float2v*>(coef + j * P1 + q1) = float2v{wc[0][j], wc[1][j]};
+      }
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
