@@ -172,6 +172,10 @@ int vsl_smooth_bwd(const float* disp, const float* img, const float* g_loss, flo
 /* Message of the last error raised on the calling thread ("" if none). */
 const char* vsl_last_error_string(void);
 
+/* Diagnostic: q[i] = a[i] / b[i] through the shared-divisor division the fused kernel uses for its sampling
+ * coordinates (device arrays of n floats); the tests compare it bit for bit with IEEE float32 division. */
+int vsl_debug_quot(const float* a, const float* b, float* q, long long n, void* stream);
+
 /* Diagnostic: workgroups of the fused kernel the runtime expects to fit on one CU for S sources. */
 int vsl_debug_fused_occupancy(int S, int avg_reprojection);
 

@@ -29,7 +29,7 @@ EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", 
            "vsl_pose_fwd", "vsl_pose_bwd", "vsl_depth_metrics_workspace_bytes", "vsl_depth_metrics",
            "vsl_warp_features_workspace_bytes", "vsl_warp_features_fwd", "vsl_warp_features_bwd",
            "vsl_mean_inv_depth_workspace_bytes", "vsl_mean_inv_depth_fwd", "vsl_mean_inv_depth_bwd",
-           "vsl_debug_fused_occupancy", "vsl_debug_time_fused", "vsl_last_error_string", "vsl_version")
+           "vsl_debug_fused_occupancy", "vsl_debug_quot", "vsl_debug_time_fused", "vsl_last_error_string", "vsl_version")
 
 
 class LossDesc(ctypes.Structure):
@@ -134,6 +134,7 @@ def _load():
         "vsl_smooth_fwd": [P, P, P, P, SZ, I, I, I, I, P],
         "vsl_smooth_bwd": [P, P, P, P, I, I, I, I, P],
         "vsl_debug_fused_occupancy": [I, I],
+        "vsl_debug_quot": [P, P, P, LL, P],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

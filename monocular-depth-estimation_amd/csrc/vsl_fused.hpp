@@ -147,6 +147,40 @@ VSL_DEV float fast_rcp(float x) {
 // sign(v) in {-1, 0, 1}.  On the device: two exact scalings by 2^126 take every non-zero finite value (denormals
 // included) beyond 1 in magnitude, the median with -1 and 1 clamps it: three instructions instead of two
 // compares, two selects and a subtraction; same values.
+// Correctly rounded float32 division with the divisor's part of the work done once.  On the device `a / b`
+// expands to: scale both operands, reciprocal, two refinement steps of the reciprocal, quotient, two residual
+// corrections, special-case fix-up -- 11 instructions, of which the reciprocal and its refinement depend on the
+// divisor only.  Divisor prepares them; quot() is the rest (6 instructions).  The operand scaling is left out: it
+// only acts when an operand or the quotient leaves about [2^-96, 2^96], which the quantities divided here
+// (camera coordinates by depth + eps, pixel coordinates by W-1 / H-1, 1 by the scaled disparity) cannot reach
+// unless they are zero, infinite or NaN, and those the fix-up instruction resolves as IEEE division does.
+// tests/test_gpu_layers.py checks it bit for bit against float32 division.  Host build: plain division.
+struct Divisor {
+  float b, r;
+};
+VSL_DEV Divisor divisor(float b) {
+#if defined(__HIPCC__)
+  float r = __builtin_amdgcn_rcpf(b);
+  const float e = fmaf(-b, r, 1.0f);
+  r = fmaf(e, r, r);
+  return Divisor{b, r};
+#else
+  return Divisor{b, 0.0f};
+#endif
+}
+VSL_DEV float quot(float a, const Divisor& d) {
+#if defined(__HIPCC__)
+  float q = a * d.r;
+  float e = fmaf(-d.b, q, a);
+  q = fmaf(e, d.r, q);
+  e = fmaf(-d.b, q, a);
+  q = fmaf(e, d.r, q);
+  return __builtin_amdgcn_div_fixupf(q, d.b, a);
+#else
+  return a / d.b;
+#endif
+}
+
 VSL_DEV float sgn(float v) {
 #if defined(__HIPCC__)
   return __builtin_amdgcn_fmed3f(v * 0x1p126f * 0x1p126f, -1.0f, 1.0f);
@@ -600,7 +634,7 @@ struct Fused {
     const float* tgtb = kp.tgt + (size_t)bk.b * 3 * HW;
     const int py = reflect_clamp(bk.y0 - HALO + ry, H);
     const float* ik = st.m.ik;
-    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    const Divisor by_wm1 = divisor((float)(W - 1)), by_hm1 = divisor((float)(H - 1));
     const float fy = (float)py;
     // rays share the y part: inv_K[i][1]*y is added after inv_K[i][0]*x in the reference's order
 #pragma unroll
@@ -615,7 +649,7 @@ struct Fused {
 
       // disp_to_depth and the back-projected ray, layers.py:21-25,163-169
       const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
-      const float D = VSL_FDIV(1.0f, sd);
+      const float D = quot(1.0f, divisor(sd));
       const float fx = (float)px;
       float X[3];
 #pragma unroll
@@ -639,9 +673,10 @@ struct Fused {
         }
         // layers.py:196-201
         const float den = VSL_FADD(cam[2], kp.eps);
-        const float u = VSL_FDIV(cam[0], den), v = VSL_FDIV(cam[1], den);
-        const float gx = VSL_FMUL(VSL_FSUB(VSL_FDIV(u, wm1), 0.5f), 2.0f);
-        const float gy = VSL_FMUL(VSL_FSUB(VSL_FDIV(v, hm1), 0.5f), 2.0f);
+        const Divisor by_den = divisor(den);
+        const float u = quot(cam[0], by_den), v = quot(cam[1], by_den);
+        const float gx = VSL_FMUL(VSL_FSUB(quot(u, by_wm1), 0.5f), 2.0f);
+        const float gy = VSL_FMUL(VSL_FSUB(quot(v, by_hm1), 0.5f), 2.0f);
         const Taps tx = axis_taps(gx, W), ty = axis_taps(gy, H);
         const float* sp = src_image(kp, s) + (size_t)bk.b * 3 * HW;
         // both x taps of a row come from one 8-byte load at min(x0, W-2)

@@ -704,6 +704,14 @@ vsl_head head_of_desc(const vsl_loss_desc* d, void* workspace, size_t workspace_
   return hd;
 }
 
+// diagnostic: the shared-divisor division of the tile program on arrays, two quotients per prepared divisor
+__global__ void vsl_debug_quot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ q, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const Divisor d = divisor(b[i]);
+    q[i] = quot(a[i], d);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -720,6 +728,17 @@ long long vsl_debug_read_stamps(void* host_out, long long max_bytes) {
 #endif
 
 // diagnostic: resident workgroups per CU the runtime predicts for the fused kernel
+int vsl_debug_quot(const float* a, const float* b, float* q, long long n, void* stream) {
+  if (!a || !b || !q || n < 0) return fail(VSL_ERR_INVALID_ARGUMENT, "debug_quot: bad arguments");
+  if (n == 0) return VSL_OK;
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(vsl_debug_quot_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                     a, b, q, n);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess)
+    return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  return VSL_OK;
+}
+
 int vsl_debug_fused_occupancy(int S, int avg) {
   int n = -1;
   auto q = [&](auto kern, int nt, size_t lds) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, nt, lds); };

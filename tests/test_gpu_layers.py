@@ -183,3 +183,38 @@ def test_per_scale_disparities_equal_the_reference_loop_when_all_scales_share_on
     for f in fids[1:]:
         assert rel(poses[f].grad, z["grad_T_%s" % f]) < 1e-5
     assert np.array_equal(outputs["identity_selection"].cpu().numpy(), z["identity_selection"])
+
+
+def test_shared_divisor_division_equals_ieee_division():
+    """The fused kernel divides camera coordinates by depth + eps, pixel coordinates by W-1 / H-1 and 1 by the scaled
+    disparity with the divisor's reciprocal prepared once (vsl_debug_quot runs that code on arrays).  Bit for bit
+    equal to float32 division over random operands with exponents in [-40, 40], the divisors the kernel meets
+    (image sizes, depths) and zero / infinite / NaN operands."""
+    import mde_amd._abi as abi
+    rng = np.random.RandomState(12)
+    n = 1 << 21
+    mant = lambda: rng.uniform(1.0, 2.0, n).astype(np.float32) * rng.choice([-1.0, 1.0], n).astype(np.float32)
+    a = mant() * np.exp2(rng.randint(-40, 41, n)).astype(np.float32)
+    b = mant() * np.exp2(rng.randint(-40, 41, n)).astype(np.float32)
+    # divisors of the kernel: W-1 / H-1 for every size up to 4096, scaled disparities, depth + eps down to cancellation
+    sizes = np.arange(1, 4096, dtype=np.float32)
+    b[:sizes.size] = sizes
+    a[:sizes.size] = rng.uniform(-5000, 5000, sizes.size).astype(np.float32)
+    k = sizes.size
+    b[k:k + 100000] = (0.01 + 9.99 * rng.uniform(0, 1, 100000)).astype(np.float32)
+    a[k:k + 100000] = 1.0
+    k += 100000
+    b[k:k + 100000] = (rng.uniform(-1, 1, 100000) * 10.0 ** rng.uniform(-14, 2, 100000)).astype(np.float32)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -3.5, 1e-30, 1e30], np.float32)
+    sa, sb = np.meshgrid(special, special)
+    a[-sa.size:], b[-sb.size:] = sa.ravel(), sb.ravel()
+    ta, tb = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)
+    q = torch.empty_like(ta)
+    abi.check(abi.lib.vsl_debug_quot(ta.data_ptr(), tb.data_ptr(), q.data_ptr(), n, torch.cuda.current_stream().cuda_stream))
+    got = q.cpu().numpy()
+    with np.errstate(all="ignore"):
+        ref = a / b
+    same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+    bad = np.flatnonzero(~same)
+    assert bad.size == 0, "%d of %d quotients differ, first: %r / %r = %r, expected %r" % (
+        bad.size, n, a[bad[0]], b[bad[0]], got[bad[0]], ref[bad[0]])
