@@ -88,6 +88,7 @@ struct KParams {
   float ssim_w3, l1_w3;  // ssim_weight/3, l1_weight/3 (channel means folded in)
   float warp_scale;
   float inv_nx, inv_ny;  // 1/(B*H*(W-1)), 1/(B*(H-1)*W)
+  float ix_scale, iy_scale;  // W/(W-1), H/(H-1): d(sample position)/d(pixel coordinate u, v) of the warp
   const float* disp;
   const float* tgt;
   const float* src[kMaxSrc];
@@ -256,7 +257,8 @@ struct Taps {
 // grid_sample(align_corners=False, padding_mode="border") along one axis:
 // unnormalise, clip, floor and fraction in float64 from the float32 grid value.
 VSL_DEV Taps axis_taps(float g, int n) {
-  double c = (((double)g + 1.0) * (double)n - 1.0) * 0.5;
+  // ((g + 1) n - 1) / 2 with the exact halving folded into the factor: same roundings, one operation less
+  double c = ((double)g + 1.0) * ((double)n * 0.5) - 0.5;
   Taps tp;
   tp.live = (c > 0.0 && c < (double)(n - 1)) ? 1.0f : 0.0f;
   double cc = fmin(fmax(c, 0.0), (double)(n - 1));
@@ -908,7 +910,10 @@ struct Fused {
     const bool remote = row < 2;
     const int iy = remote ? row + TH - 2 : row - 2;
     // one combined test (no short-circuit): nested early exits make the compiler re-zero all partial sums at every level
-    if ((int)(ip < 0) | (int)(ip >= TW / 2) | (int)(bk.y0 + iy >= kp.H) | (int)(bk.x0 + 2 * ip >= kp.W)) return;
+    const bool off_tile = (unsigned)ip >= (unsigned)(TW / 2);  // covers ip < 0 as well
+    const bool off_image = bk.y0 + iy >= kp.H;
+    const bool off_row = bk.x0 + 2 * ip >= kp.W;
+    if (off_tile | off_image | off_row) return;
     Chain chn[2][S];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
@@ -949,7 +954,6 @@ struct Fused {
         }
       }
       const float* ikm = st.m.ik;
-      const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
 
       float gD[2] = {0.0f, 0.0f};
       float gcs[S][2][3];  // d L / d cam of (source, pixel); the 3x4 projection gradient is built from it at the end
@@ -1082,7 +1086,7 @@ struct Fused {
             continue;
           }
           // d ix / d gx = W/2, d gx / d u = 2/(W-1)
-          const float gu = gix[k] * ((float)W / wm1), gv = giy[k] * ((float)H / hm1);
+          const float gu = gix[k] * kp.ix_scale, gv = giy[k] * kp.iy_scale;
           // projection of this pixel again (layers.py:193-196); gradient only, so a plain reciprocal
           float cam[3];
 #pragma unroll

@@ -565,6 +565,8 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
   kp.c_disp = (float)(1.0 / (double)d->min_depth - 1.0 / (double)d->max_depth);
   kp.inv_nx = (float)(1.0 / ((double)d->B * d->H * (d->W - 1)));
   kp.inv_ny = (float)(1.0 / ((double)d->B * (d->H - 1) * d->W));
+  kp.ix_scale = (float)d->W / (float)(d->W - 1);
+  kp.iy_scale = (float)d->H / (float)(d->H - 1);
   kp.K = d->K;
   kp.invK = d->inv_K;
   kp.want_grad = want_grad;

@@ -34,6 +34,7 @@ class KParams(ctypes.Structure):
         ("cst_ssim", ctypes.c_float), ("cst_l1", ctypes.c_float),
         ("ssim_w3", ctypes.c_float), ("l1_w3", ctypes.c_float), ("warp_scale", ctypes.c_float),
         ("inv_nx", ctypes.c_float), ("inv_ny", ctypes.c_float),
+        ("ix_scale", ctypes.c_float), ("iy_scale", ctypes.c_float),
         ("disp", ctypes.c_void_p), ("tgt", ctypes.c_void_p), ("src", ctypes.c_void_p * MAX_SRC),
         ("K", ctypes.c_void_p), ("invK", ctypes.c_void_p), ("T", ctypes.c_void_p * MAX_SRC),
         ("noise", ctypes.c_void_p), ("seed", ctypes.c_ulonglong), ("idmin", ctypes.c_void_p),
@@ -84,6 +85,8 @@ def run_emu(disp, target, sources, K, inv_K, Ts, noise, automask=True, avg=False
     kp.warp_scale = warp_scale
     kp.inv_nx = 1.0 / (B * H * (W - 1))
     kp.inv_ny = 1.0 / (B * (H - 1) * W)
+    kp.ix_scale = np.float32(W) / np.float32(W - 1)
+    kp.iy_scale = np.float32(H) / np.float32(H - 1)
     kp.disp, kp.tgt, kp.K, kp.invK = _ptr(disp), _ptr(target), _ptr(K), _ptr(inv_K)
     for s in range(S):
         kp.src[s] = _ptr(sources[s])
