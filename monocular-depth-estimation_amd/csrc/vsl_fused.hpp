@@ -473,6 +473,23 @@ struct Ident {
     const unsigned HW = (unsigned)kp.H * (unsigned)kp.W;
     const float* tgtb = kp.tgt + (size_t)bk.b * 3 * HW;
     const int py = reflect_clamp(bk.y0 - 1 + ry, kp.H);
+    // Tiles whose grown region lies inside the image horizontally (all but the first and last of a row) need no
+    // reflection in x: the two pixels of a pair are neighbours in memory and come from one 8-byte load per plane.
+    if (bk.x0 >= 1 && bk.x0 + TW + 1 <= kp.W) {
+      const unsigned off = ((unsigned)py * (unsigned)kp.W + (unsigned)(bk.x0 - 1 + rx0)) << 2;
+      float* row = lds + ry * RW + rx0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const TexelPair t = load_texel_pair_at(tgtb + (size_t)c * HW, off);
+        *reinterpret_cast<float2v*>(row + c * PN) = float2v{t.lo, t.hi};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const TexelPair v = load_texel_pair_at(src_image(kp, s) + ((size_t)bk.b * 3 + c) * HW, off);
+          *reinterpret_cast<float2v*>(row + (3 + s * 3 + c) * PN) = float2v{v.lo, v.hi};
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int px = reflect_clamp(bk.x0 - 1 + rx0 + k, kp.W);
@@ -498,9 +515,12 @@ struct Ident {
     for (int s = 0; s < S; ++s) fsum[s][0] = fsum[s][1] = lsum[s][0] = lsum[s][1] = 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float yw[3][4], sy[2], syy[2];
+      float yw[3][4], dy[3][4], sy[2], syy[2];
       load_win(lds + c * PN, base, RW, yw);
-      if (!kp.no_ssim) y_stats(yw, sy, syy);
+      if (!kp.no_ssim) {
+        y_diffs(yw, dy);
+        y_stats_d(dy, sy, syy);
+      }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         float xw[3][4];
@@ -509,7 +529,7 @@ struct Ident {
         lsum[s][1] += fabsf(yw[1][2] - xw[1][2]);
         if (!kp.no_ssim) {
           SsimOut o[2];
-          ssim_pair(xw, yw, sy, syy, false, o);
+          ssim_pair_d(xw, yw[1][1], dy, sy, syy, false, o);
           fsum[s][0] += o[0].f;
           fsum[s][1] += o[1].f;
         }
