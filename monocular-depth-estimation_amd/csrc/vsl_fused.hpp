@@ -1220,37 +1220,38 @@ struct Fused {
     }
     bool warped_wins[2] = {false, false};
     float rsum[2] = {0.0f, 0.0f};
-    float sy[3][2], syy[3][2];
-    if (!kp.no_ssim) {
+    // channel by channel, the target window's differences and statistics shared by all sources (as in phase 2)
+    float fsum[S][2], lsum[S][2];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float yw[3][4];
-        load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
-        y_stats(yw, sy[c], syy[c]);
-        VSL_SCHED_FENCE();
+    for (int s = 0; s < S; ++s) fsum[s][0] = fsum[s][1] = lsum[s][0] = lsum[s][1] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float yw[3][4], dy[3][4], sy[2], syy[2];
+      load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
+      if (!kp.no_ssim) {
+        y_diffs(yw, dy);
+        y_stats_d(dy, sy, syy);
       }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float xw[3][4];
+        load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
+        lsum[s][0] += fabsf(yw[1][1] - xw[1][1]);
+        lsum[s][1] += fabsf(yw[1][2] - xw[1][2]);
+        if (!kp.no_ssim) {
+          SsimOut o[2];
+          ssim_pair_d(xw, yw[1][1], dy, sy, syy, false, o);
+          fsum[s][0] += o[0].f;
+          fsum[s][1] += o[1].f;
+        }
+      }
+      VSL_SCHED_FENCE();
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      float fsum[2] = {0.0f, 0.0f}, lsum[2] = {0.0f, 0.0f};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float yw[3][4], xw[3][4];
-        load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
-        load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
-        lsum[0] += fabsf(yw[1][1] - xw[1][1]);
-        lsum[1] += fabsf(yw[1][2] - xw[1][2]);
-        if (!kp.no_ssim) {
-          SsimOut o[2];
-          ssim_pair(xw, yw, sy[c], syy[c], false, o);
-          fsum[0] += o[0].f;
-          fsum[1] += o[1].f;
-        }
-        VSL_SCHED_FENCE();
-      }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        float e = kp.no_ssim ? lsum[k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[k], kp.l1_w3 * lsum[k]);
+        float e = kp.no_ssim ? lsum[s][k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[s][k], kp.l1_w3 * lsum[s][k]);
         e *= kp.warp_scale;
         if (AVG) {
           rsum[k] += e;
