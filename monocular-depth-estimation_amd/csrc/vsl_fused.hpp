@@ -248,6 +248,26 @@ VSL_DEV TexelPair load_texel_pair_at(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const TexelPair*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// 3 rows x NC consecutive floats starting at float offset `base` of an LDS plane (any alignment)
+template <int NC>
+VSL_DEV void load_cols(const float* plane, int base, int pitch, float w[3][NC]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) w[r][j] = plane[base + r * pitch + j];
+}
+
+#if defined(__HIPCC__)
+// the value the lane to the left / right (within its group of 16 lanes, i.e. the neighbouring pixel pair of the same
+// tile row) holds: one data-parallel-primitive move, usually folded into the instruction that consumes it
+VSL_DEV float lane_left(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));
+}
+VSL_DEV float lane_right(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true));
+}
+#endif
+
 struct Taps {
   int i0, i1;
   float t;
@@ -933,7 +953,12 @@ struct Fused {
     const bool off_tile = (unsigned)ip >= (unsigned)(TW / 2);  // covers ip < 0 as well
     const bool off_image = bk.y0 + iy >= kp.H;
     const bool off_row = bk.x0 + 2 * ip >= kp.W;
-    if (off_tile | off_image | off_row) return;
+    // On the device the threads of a tile row form the column sums of the coefficient gather together (each its own
+    // two columns, see below), so the pairs outside the tile or the image stay until that is done.
+    const bool inactive = off_tile | off_image | off_row;
+#if !defined(__HIPCC__)
+    if (inactive) return;
+#endif
     Chain chn[2][S];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
@@ -982,25 +1007,33 @@ struct Fused {
       // Every coefficient plane is read once; its window is split between the sources by 0/1 masks of the
       // selection plane (x the row fold on border tiles).  Column sums first, then the two overlapping
       // windows of the pixel pair.
+      // A pixel pair needs the sums of four window columns (its own two and one on either side).  The host build
+      // forms all four; on the device a thread forms the two columns of its own pixels and takes the outer two from
+      // the neighbouring lanes, which hold exactly those sums: half the multiply-adds, masks and LDS reads.
+#if defined(__HIPCC__)
+      constexpr int NC = 2, J0 = 1;
+#else
+      constexpr int NC = 4, J0 = 0;
+#endif
       float g[S][2][3];
       {
-        float mf[S][3][4];
+        float mf[S][3][NC];
         {
-          float sw[3][4];
-          load_win(sel, qb, R1W, sw);
+          float sw[3][NC];
+          load_cols<NC>(sel, qb + J0, R1W, sw);
 #pragma unroll
           for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) mf[s][i][j] = AVG ? (float)(sw[i][j] > 0.0f) : (float)(sw[i][j] == (float)s);
+              for (int j = 0; j < NC; ++j) mf[s][i][j] = AVG ? (float)(sw[i][j] > 0.0f) : (float)(sw[i][j] == (float)s);
         }
-        // (row 1 of the masks is never folded, so mf[s][1][1 + k] stays the mask of the pixel's own window)
+        // (row 1 of the masks is never folded, so mf[s][1][1 + k - J0] stays the mask of the pixel's own window)
         if (border) {
 #pragma unroll
           for (int s = 0; s < (AVG ? 1 : S); ++s)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NC; ++j) {
               mf[s][0][j] *= fy[0];
               mf[s][2][j] *= fy[2];
             }
@@ -1020,16 +1053,21 @@ struct Fused {
           if (!kp.no_ssim) {
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
-              float cw[3][4];
-              if (!AVG) load_win(coef + (c * 3 + e) * P1, qb, R1W, cw);
+              float cw[3][NC];
+              if (!AVG) load_cols<NC>(coef + (c * 3 + e) * P1, qb + J0, R1W, cw);
 #pragma unroll
               for (int s = 0; s < S; ++s) {
-                if (AVG) load_win(coef + (s * 9 + c * 3 + e) * P1, qb, R1W, cw);
+                if (AVG) load_cols<NC>(coef + (s * 9 + c * 3 + e) * P1, qb + J0, R1W, cw);
                 const int ms = AVG ? 0 : s;  // avg_reprojection: one mask (warped beats identity) for all sources
-                float col[4];
+                float own[NC];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                  col[j] = fmaf(mf[ms][2][j], cw[2][j], fmaf(mf[ms][1][j], cw[1][j], mf[ms][0][j] * cw[0][j]));
+                for (int j = 0; j < NC; ++j)
+                  own[j] = fmaf(mf[ms][2][j], cw[2][j], fmaf(mf[ms][1][j], cw[1][j], mf[ms][0][j] * cw[0][j]));
+#if defined(__HIPCC__)
+                const float col[4] = {lane_left(own[1]), own[0], own[1], lane_right(own[0])};
+#else
+                const float col[4] = {own[0], own[1], own[2], own[3]};
+#endif
                 float a2[2];
                 if (!border) {
                   two_windows(col, a2);
@@ -1047,10 +1085,13 @@ struct Fused {
           for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int k = 0; k < 2; ++k)
-              g[s][k][c] = hv.cst_ssim * gs[s][k] - hv.cst_l1 * mf[AVG ? 0 : s][1][1 + k] * sgn(yv[k] - xv[s][k]);
+              g[s][k][c] = hv.cst_ssim * gs[s][k] - hv.cst_l1 * mf[AVG ? 0 : s][1][1 + k - J0] * sgn(yv[k] - xv[s][k]);
           VSL_SCHED_FENCE();
         }
       }
+#if defined(__HIPCC__)
+      if (inactive) return;
+#endif
 
       float D[2], r[2][3];
 #pragma unroll
