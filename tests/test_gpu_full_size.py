@@ -19,9 +19,10 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-def oracle_run(data, fids, B, H, W, head=0, warp_scale=1.0, scales=(0,)):
+def oracle_run(data, fids, B, H, W, head=0, warp_scale=1.0, scales=(0,), automask=True, avg=False, no_ssim=False):
     from oracle import vsl_oracle as O
-    cfg = O.LossConfig(frame_ids=fids, scales=list(scales), height=H, width=W, automask=True, warp_scale=warp_scale)
+    cfg = O.LossConfig(frame_ids=fids, scales=list(scales), height=H, width=W, automask=automask, warp_scale=warp_scale,
+                       avg_reprojection=avg, no_ssim=no_ssim)
     inputs = {"K": data["K"], "inv_K": data["inv_K"]}
     for f in fids:
         inputs[("image", f)] = data[("image", f)].double()
@@ -35,7 +36,8 @@ def oracle_run(data, fids, B, H, W, head=0, warp_scale=1.0, scales=(0,)):
             inputs["stereo_T"] = T
         else:
             outputs[("cam_T_cam", f)] = T
-    losses = O.loss_forward_backward(inputs, outputs, cfg, data["noise"])
+    noise = data["noise"][:, :1].contiguous() if avg else data["noise"]
+    losses = O.loss_forward_backward(inputs, outputs, cfg, noise)
     # Pixels whose derivative is decided by a comparison that float32 cannot resolve (the reference evaluates the
     # warp and the errors in float64, the kernels in float32); they are compared separately:
     #  - |target - warped| of some channel below float32 resolution: sign of the L1 term (Trainer.py:487), a jump
@@ -44,31 +46,38 @@ def oracle_run(data, fids, B, H, W, head=0, warp_scale=1.0, scales=(0,)):
     #    the winner may differ, which changes the SSIM gradient of the 3x3 neighbourhood.
     amb = torch.zeros(B, H, W, dtype=torch.bool)
     with torch.no_grad():
-        cand = []
+        cand, ident = [], []
         for f in fids[1:]:
             amb |= ((inputs[("image", 0)] - outputs[("color", f)]).abs() < 2e-7).any(1)
-            cand.append(O.reprojection_error(outputs[("color", f)], inputs[("image", 0)]) * warp_scale)
-        for f in fids[1:]:
-            cand.append(O.reprojection_error(inputs[("image", f)], inputs[("image", 0)]))
-        cand = torch.cat(cand, 1)
-        cand[:, len(fids) - 1:] += data["noise"].double() * 1e-5
-        two = torch.topk(cand, 2, dim=1, largest=False).values
-        tie = ((two[:, 1] - two[:, 0]) < 2e-7).float().unsqueeze(1)
-        amb |= torch.nn.functional.max_pool2d(tie, 3, 1, 1)[:, 0] > 0
-    return losses, disp.grad, {f: poses[f].grad for f in fids[1:]}, outputs["identity_selection"], amb
+            cand.append(O.reprojection_error(outputs[("color", f)], inputs[("image", 0)], no_ssim) * warp_scale)
+            ident.append(O.reprojection_error(inputs[("image", f)], inputs[("image", 0)], no_ssim))
+        cand, ident = torch.cat(cand, 1), torch.cat(ident, 1)
+        if avg:
+            cand, ident = cand.mean(1, keepdim=True), ident.mean(1, keepdim=True)
+        if automask:
+            cand = torch.cat([cand, ident + noise.double() * 1e-5], 1)
+        if cand.shape[1] > 1:
+            two = torch.topk(cand, 2, dim=1, largest=False).values
+            tie = ((two[:, 1] - two[:, 0]) < 2e-7).float().unsqueeze(1)
+            # with SSIM the winner of a pixel's window enters the gradient of its 3x3 neighbourhood; L1 alone is local
+            amb |= (tie if no_ssim else torch.nn.functional.max_pool2d(tie, 3, 1, 1))[:, 0] > 0
+    sel = outputs["identity_selection"] if automask else None
+    return losses, disp.grad, {f: poses[f].grad for f in fids[1:]}, sel, amb
 
 
-def gpu_run(data, fids, head=0, warp_scale=1.0, scales=(0,), noise=True):
+def gpu_run(data, fids, head=0, warp_scale=1.0, scales=(0,), noise=True, automask=True, avg=False, no_ssim=False):
     from mde_amd.ops import fused_view_synthesis_loss
     disp = data[("disp", head)].to(DEV).requires_grad_(True)
     poses = [(data["stereo_T"] if f == "s" else data[("cam_T_cam", f)]).to(DEV).requires_grad_(True) for f in fids[1:]]
     losses, ident = fused_view_synthesis_loss(
         disp, data[("image", 0)].to(DEV), [data[("image", f)].to(DEV) for f in fids[1:]], data["K"].to(DEV),
-        data["inv_K"].to(DEV), poses, data["noise"].to(DEV) if noise else None,
+        data["inv_K"].to(DEV), poses,
+        (data["noise"][:, :1].contiguous() if avg else data["noise"]).to(DEV) if noise else None,
+        automask=automask, avg_reprojection=avg, no_ssim=no_ssim,
         scale_weights=[1e-3 / 2 ** s for s in scales], warp_scale=warp_scale)
     losses[0].backward()
     torch.cuda.synchronize()
-    return losses.detach().cpu(), disp.grad.cpu(), [p.grad.cpu() for p in poses], ident.cpu()
+    return losses.detach().cpu(), disp.grad.cpu(), [p.grad.cpu() for p in poses], ident.cpu() if automask else None
 
 
 CONFIGS = {
@@ -77,22 +86,28 @@ CONFIGS = {
     "c2_640x192_b12_scales4": (12, 192, 640, [0, -1, 1], 1.0, (0, 1, 2, 3)),
     "c3_1024x320_b12_stereo": (12, 320, 1024, [0, -1, 1, "s"], 1.0, (0,)),
     "c5_1280x384_b8_distillation": (8, 384, 1280, [0, -1, 1], 0.9, (0,)),
+    # the option flags of the path at a benchmark size (options.py:120-138)
+    "c2_640x192_b4_avg_reprojection": (4, 192, 640, [0, -1, 1], 1.0, (0,), dict(avg=True)),
+    "c2_640x192_b4_no_ssim": (4, 192, 640, [0, -1, 1], 1.0, (0,), dict(no_ssim=True)),
+    "c2_640x192_b4_no_automask": (4, 192, 640, [0, -1, 1], 1.0, (0,), dict(automask=False)),
+    "c3_1024x320_b2_stereo_avg_no_automask": (2, 320, 1024, [0, -1, 1, "s"], 1.0, (0,), dict(avg=True, automask=False)),
 }
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_config_matches_oracle(name):
     import mde_amd.synth as synth
-    B, H, W, fids, kappa, scales = CONFIGS[name]
+    B, H, W, fids, kappa, scales = CONFIGS[name][:6]
+    flags = CONFIGS[name][6] if len(CONFIGS[name]) > 6 else {}
     torch.set_num_threads(16)
     data = synth.make_batch(B, H, W, fids, seed=7)
-    ref, g_ref, gT_ref, sel_ref, amb = oracle_run(data, fids, B, H, W, warp_scale=kappa, scales=scales)
-    losses, g, gT, sel = gpu_run(data, fids, warp_scale=kappa, scales=scales)
+    ref, g_ref, gT_ref, sel_ref, amb = oracle_run(data, fids, B, H, W, warp_scale=kappa, scales=scales, **flags)
+    losses, g, gT, sel = gpu_run(data, fids, warp_scale=kappa, scales=scales, **flags)
     assert abs(losses[0].item() - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
     for i, s in enumerate(scales):
         assert abs(losses[3 + i].item() - ref["loss/%d" % s].item()) <= TOL * abs(ref["loss/%d" % s].item())
     n_amb = int(amb.sum())
-    assert n_amb <= max(2, int(4e-5 * amb.numel())), "too many float32-ambiguous pixels: %d" % n_amb
+    assert n_amb <= max(2, int(1e-4 * amb.numel())), "too many float32-ambiguous pixels: %d" % n_amb
     keep = (~amb).unsqueeze(1).float()
     err_g = rel((g * keep).numpy(), (g_ref * keep).numpy())
     assert err_g <= TOL, "grad_disp relative error %.3e (%d ambiguous pixels left out)" % (err_g, n_amb)
@@ -110,8 +125,9 @@ def test_config_matches_oracle(name):
         msg = "grad_T[%s] relative errors %s" % (f, ["%.1e" % e for e in errs])
         assert len(bad) <= max(1, B // 2), msg
         assert all(n_amb_img[b] > 0 and errs[b] <= 2e-2 for b in bad), msg
-    flips = int((sel.numpy() != sel_ref.numpy()).sum())
-    assert flips == 0, "%d identity_selection flips" % flips
+    if sel_ref is not None:
+        flips = int((sel.numpy() != sel_ref.numpy()).sum())
+        assert flips == 0, "%d identity_selection flips" % flips
 
 
 def _desc(abi, t, B, H, W, fids, head, flags, idmin=None, warp_scale=1.0):
