@@ -77,6 +77,8 @@ constexpr float kC2 = 0.03f * 0.03f;
 // number of per-block partial sums: photo, sum(disp), Sx, Sy, then 12 per source
 constexpr int num_partials(int S) { return 4 + 12 * S; }
 constexpr int kPartStride = 4 + 12 * kMaxSrc;  // stride of one block's record in the workspace
+constexpr int kPrepStride = 64;                 // floats per image in KParams::prep: 12 per source, then inv_K[:3,:3]
+constexpr int kPrepInvK = 12 * kMaxSrc;
 
 struct KParams {
   int B, H, W, S;
@@ -104,6 +106,8 @@ struct KParams {
   float* ident_sel;  // [B,H,W] or null
   float* partials;   // [blocks][kPartStride]
   unsigned int* counter;  // arrival counter of the finalize kernel, cleared here
+  float* prep;       // [B][kPrepStride] per-image projection matrices and inv_K, written by prepare_matrices() in a
+                     // launch before the tile programs, or null: every workgroup then forms them itself
   int want_grad;
 #ifdef VSL_STAMPS
   unsigned long long* stamps;  // diagnostic build: [blocks][waves][16] shader-clock samples
@@ -224,6 +228,17 @@ VSL_DEV const float* src_pose(const KParams& kp, int s) {
   if (s == 2) p = kp.T[2];
   if (s == 3) p = kp.T[3];
   return p;
+}
+
+// Entry `e` of image b's record in KParams::prep: P = (K @ T)[:3,:] of every source, then inv_K[:3,:3].
+VSL_DEV float prep_entry(const KParams& kp, int b, int e) {
+  if (e < kPrepInvK) {
+    const int s = e / 12, q = e % 12;
+    if (s >= kp.S) return 0.0f;
+    return proj_entry(kp.K + 16 * b, src_pose(kp, s) + 16 * b, q / 4, q % 4);
+  }
+  const int q = e - kPrepInvK;
+  return q < 9 ? kp.invK[16 * b + (q / 3) * 4 + (q % 3)] : 0.0f;
 }
 
 struct alignas(8) float2v {
@@ -630,32 +645,20 @@ struct Fused {
 
   // ---- phase 0: projection matrices (layers.py:189) and inv_K into wave-uniform registers -----------
   static VSL_DEV void phase0(const KParams& kp, const HeadView& hv, const Block& bk, int tid, ThreadState<S>& st) {
-    if (tid == 0 && bk.b == 0 && bk.x0 == 0 && bk.y0 == 0 && hv.counter) *hv.counter = 0u;
 #if defined(__HIPCC__)
-    const int lane = tid & 63;
-    float v = 0.0f;
-    if (lane < 12 * S) {
-      // the pose pointer is picked with compile-time indices: indexing the by-value argument struct with a
-      // per-lane value would move the whole struct into scratch memory
-      const float* Tp = kp.T[0];
-#pragma unroll
-      for (int s = 1; s < S; ++s)
-        if (lane >= 12 * s) Tp = src_pose(kp, s);
-      const int e = lane % 12;
-      v = proj_entry(kp.K + 16 * bk.b, Tp + 16 * bk.b, e / 4, e % 4);
-    } else if (lane < 12 * S + 9) {
-      const int e = lane - 12 * S;
-      v = kp.invK[16 * bk.b + (e / 3) * 4 + (e % 3)];
-    }
+    // Prepared by an earlier launch on the same stream (the launcher always sets KParams::prep). The image index
+    // is uniform, so these are scalar loads straight into wave-uniform registers; they come before any store of
+    // this kernel.
+    const float* pp = kp.prep + (size_t)bk.b * kPrepStride;
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
-      for (int e = 0; e < 12; ++e)
-        st.m.P[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s * 12 + e));
+      for (int e = 0; e < 12; ++e) st.m.P[s][e] = pp[s * 12 + e];
 #pragma unroll
-    for (int e = 0; e < 9; ++e)
-      st.m.ik[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 12 * S + e));
+    for (int e = 0; e < 9; ++e) st.m.ik[e] = pp[kPrepInvK + e];
+    if (tid == 0 && bk.b == 0 && bk.x0 == 0 && bk.y0 == 0 && hv.counter) *hv.counter = 0u;
 #else
+    if (tid == 0 && bk.b == 0 && bk.x0 == 0 && bk.y0 == 0 && hv.counter) *hv.counter = 0u;
     for (int s = 0; s < S; ++s)
       for (int e = 0; e < 12; ++e) st.m.P[s][e] = proj_entry(kp.K + 16 * bk.b, src_pose(kp, s) + 16 * bk.b, e / 4, e % 4);
     for (int e = 0; e < 9; ++e) st.m.ik[e] = kp.invK[16 * bk.b + (e / 3) * 4 + (e % 3)];

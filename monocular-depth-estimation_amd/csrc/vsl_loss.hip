@@ -196,10 +196,19 @@ __global__ __launch_bounds__(kIdNT) void vsl_ident_kernel(const KParams kp) {
   __shared__ __align__(16) float lds[I::LDS_FLOATS];
   typename I::Block bk;
   int head = 0;
+  // this launch precedes the tile programs of the step: its first workgroup also writes the per-image matrices
+  if (kp.prep && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < kp.B * kPrepStride; i += kIdNT) kp.prep[i] = prep_entry(kp, i / kPrepStride, i % kPrepStride);
   if (swizzled_tile<kIdTH>(kp, 1, head, bk.b, bk.x0, bk.y0) < 0) return;
   I::load(kp, bk, threadIdx.x, lds);
   __syncthreads();
   I::compute(kp, bk, threadIdx.x, lds);
+}
+
+// the per-image matrices alone, for steps that launch no identity pass (no auto-masking, or a shared identity minimum)
+__global__ void vsl_prep_kernel(const KParams kp) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kp.B * kPrepStride; i += gridDim.x * blockDim.x)
+    kp.prep[i] = prep_entry(kp, i / kPrepStride, i % kPrepStride);
 }
 
 // --------------------------------------------------------------------------
@@ -380,7 +389,7 @@ inline unsigned swizzled_grid(int tiles) { return 8u * (unsigned)((tiles + 7) / 
 
 struct Layout {
   int tiles_x, tiles_y, tiles_per_image, blocks;
-  size_t off_partials, off_gphoto, off_gedge, off_idmin, off_img, off_gT, off_c12, off_counter, total;
+  size_t off_partials, off_gphoto, off_gedge, off_idmin, off_img, off_gT, off_c12, off_counter, off_prep, total;
 };
 
 inline int desc_tile_h(const vsl_loss_desc* d) {
@@ -410,6 +419,8 @@ Layout make_layout(int B, int H, int W, int th) {
   o += align256((size_t)kMaxSrc * B * 16 * sizeof(float));
   L.off_c12 = o;
   o += align256((size_t)B * 2 * sizeof(float));
+  L.off_prep = o;
+  o += align256((size_t)B * kPrepStride * sizeof(float));
   L.total = o;
   return L;
 }
@@ -622,13 +633,15 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
     kp.stamps = g_stamps;
   }
 #endif
-  if (automask) {
-    if (d->identity_min) {
-      kp.idmin = const_cast<float*>(d->identity_min);
-    } else {  // computed once into the first head's workspace and read by every head
-      kp.idmin = (float*)((char*)heads[0].workspace + L.off_idmin);
-      launch_ident(kp, avg, dim3(swizzled_grid(make_layout(d->B, d->H, d->W, kIdTH).blocks)), stream);
-    }
+  // per-image projection matrices, shared by all heads: written by the identity pass when there is one
+  kp.prep = (float*)((char*)heads[0].workspace + L.off_prep);
+  if (automask && !d->identity_min) {  // computed once into the first head's workspace and read by every head
+    kp.idmin = (float*)((char*)heads[0].workspace + L.off_idmin);
+    launch_ident(kp, avg, dim3(swizzled_grid(make_layout(d->B, d->H, d->W, kIdTH).blocks)), stream);
+  } else {
+    if (automask) kp.idmin = const_cast<float*>(d->identity_min);
+    hipLaunchKernelGGL(vsl_prep_kernel, dim3((d->B * kPrepStride + 255) / 256 > 64 ? 64 : (d->B * kPrepStride + 255) / 256), dim3(256), 0,
+                       stream, kp);
   }
   int rc = VSL_OK;
   if (ev0) (void)hipEventRecord(ev0, stream);

@@ -39,7 +39,8 @@ class KParams(ctypes.Structure):
         ("K", ctypes.c_void_p), ("invK", ctypes.c_void_p), ("T", ctypes.c_void_p * MAX_SRC),
         ("noise", ctypes.c_void_p), ("seed", ctypes.c_ulonglong), ("idmin", ctypes.c_void_p),
         ("gphoto", ctypes.c_void_p), ("gedge", ctypes.c_void_p), ("ident_sel", ctypes.c_void_p),
-        ("partials", ctypes.c_void_p), ("counter", ctypes.c_void_p), ("want_grad", ctypes.c_int),
+        ("partials", ctypes.c_void_p), ("counter", ctypes.c_void_p), ("prep", ctypes.c_void_p),
+        ("want_grad", ctypes.c_int),
     ]
 
 
