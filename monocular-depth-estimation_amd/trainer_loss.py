@@ -133,6 +133,16 @@ class ViewSynthesisLoss:
         drop = torch.where(keep == 1.0, input_, torch.ones_like(target))
         return torch.mean((input_ - target * drop) ** 2)
 
+    # ------------------------------------------------------------------ Trainer_distilation.py:1076-1110
+    def compute_affinity_huber_loss(self, input_, t_seg, target, weight=None):
+        """The distillation trainer's variant of the affinity loss: Huber (delta 1, mean) between the warped map
+        and the target frame's, times the fraction of pixels whose target channels sum to less than 24;
+        ``t_seg`` and ``weight`` do not enter the value.  Elementwise torch ops on the device."""
+        target = target.to(input_.device)
+        huber = F.huber_loss(input_, target.to(input_.dtype))
+        frac = (target.sum(1, keepdim=True) < 24).to(input_.dtype).mean()
+        return huber * frac
+
     def _affinity_term(self, inputs, outputs, disp, poses, drop_rand):
         """Sum over the sources of the affinity loss (Trainer.py:546-548), each map warped by the fused
         disp -> depth -> backproject -> project -> sample pass so that the gradient reaches disp and the poses."""

@@ -315,6 +315,27 @@ def run_affinity_case(layers, trainer, out_dir):
     print("affinity/%s.npz  loss=%.10f" % (c["name"], float(rec["loss"])))
 
 
+def run_affinity_huber_case(distil, out_dir):
+    """Trainer_distilation.Trainer.compute_affinity_reprojection_loss (:1076-1110) called directly (no caller exists
+    in that trainer): a float64 prediction as grid_sample of a float64 map returns it, a near-binary float32 target
+    whose channel sums straddle the threshold 24 of :1084."""
+    B, H, W = 2, 24, 80
+    box = lambda a: torch.nn.functional.avg_pool3d(torch.nn.functional.pad(a, (1, 1, 1, 1, 0, 0), mode="replicate"), (1, 3, 3), 1)[:, 0]
+    pred = box(torch.from_numpy(synth.uniform(120, (B, 1, 25, H, W)).astype(np.float32)))
+    pred = (pred * 3.0 - 1.0).double().clone().requires_grad_(True)     # |pred - target| crosses delta = 1
+    target = (box(torch.from_numpy(synth.uniform(121, (B, 1, 25, H, W)).astype(np.float32))) > 0.36).float().contiguous()
+    tr = object.__new__(distil.Trainer)
+    loss = tr.compute_affinity_reprojection_loss(pred, None, target, [1.5, 0.5])
+    loss.backward()
+    frac = float((target.sum(1) < 24).float().mean())
+    lin = float(((pred.detach() - target).abs() >= 1).float().mean())
+    os.makedirs(os.path.join(out_dir, "affinity"), exist_ok=True)
+    np.savez_compressed(os.path.join(out_dir, "affinity", "huber_b2_24x80.npz"), pred=pred.detach().numpy().astype(np.float32),
+                        target=target.numpy(), loss=loss.detach().numpy(), grad_pred=pred.grad.numpy())
+    print("affinity/huber_b2_24x80.npz  loss=%.10f  pixels below the threshold %.1f %%  linear branch %.1f %%" % (
+        float(loss), 100 * frac, 100 * lin))
+
+
 def run_depth_metric_cases(layers, trainer, out_dir):
     """Trainer.compute_depth_losses (Trainer.py:622-662) on a predicted depth and a sparse 375 x 1242 ground truth
     (LiDAR-like: a few percent of the pixels carry a value)."""
@@ -379,6 +400,7 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     if "--affinity-only" in sys.argv:
         run_affinity_case(layers, trainer, out_dir)
+        run_affinity_huber_case(distil, out_dir)
         return
     if "--metrics-only" in sys.argv:
         run_depth_metric_cases(layers, trainer, out_dir)
@@ -391,6 +413,7 @@ def main():
         return
     run_feature_warp_cases(layers, out_dir)
     run_affinity_case(layers, trainer, out_dir)
+    run_affinity_huber_case(distil, out_dir)
     run_depth_metric_cases(layers, trainer, out_dir)
     for c in CASES:
         path, loss, g = run_case(c, layers, trainer, distil, out_dir)

@@ -238,6 +238,17 @@ def affinity_reprojection_loss(pred: torch.Tensor, target: torch.Tensor, weight:
     return torch.mean((pred - target * drop) ** 2)
 
 
+def affinity_huber_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Trainer_distilation.py:1076-1110 -- the distillation trainer's variant: Huber loss (delta 1, mean over all
+    elements) between the warped map and the target frame's, times the fraction of pixels whose 25 target channels
+    sum to less than 24 (:1081-1084; the scalar Huber value is broadcast over that [B,1,H,W] indicator and the
+    product averaged, :1104-1110).  ``t_seg`` and ``weight`` of the reference's signature do not enter the value."""
+    d = (pred - target.to(pred.dtype)).abs()
+    huber = torch.where(d < 1.0, 0.5 * d * d, d - 0.5).mean()
+    frac = (target.sum(1, keepdim=True) < 24).to(pred.dtype).mean()
+    return huber * frac
+
+
 def compute_losses(inputs: Dict, outputs: Dict, cfg: LossConfig,
                    noise: Optional[torch.Tensor] = None, drop_rand: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """Trainer.py:518-620 (predictive-mask branch excluded).

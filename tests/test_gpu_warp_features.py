@@ -176,3 +176,22 @@ def test_affinity_term_matches_reference_fixture():
     plain = vs.compute_losses(inputs, {("disp", 0): disp.detach(), **{("cam_T_cam", f): poses[f].detach() for f in fids[1:]}},
                               noise=torch.from_numpy(z["noise"]).to(DEV))
     assert plain["loss"].item() < losses["loss"].item()
+
+
+@pytest.mark.gpu
+def test_affinity_huber_variant_matches_reference_fixture():
+    """ViewSynthesisLoss.compute_affinity_huber_loss against Trainer_distilation.py:1076-1110 run on the CPU in
+    float64: value and gradient within 1e-5 relative."""
+    import types
+    from mde_amd.trainer_loss import ViewSynthesisLoss
+    z = np.load(os.path.join(GOLDEN_DIR, "affinity", "huber_b2_24x80.npz"), allow_pickle=False)
+    opt = types.SimpleNamespace(scales=[0], frame_ids=[0, -1, 1], height=24, width=80, min_depth=0.1, max_depth=100.0,
+                                disable_automasking=False, avg_reprojection=False, no_ssim=False,
+                                disparity_smoothness=1e-3, pose_model_type="shared")
+    vs = ViewSynthesisLoss(opt, use_affinity=True)
+    pred = torch.from_numpy(z["pred"]).to(DEV).requires_grad_(True)
+    loss = vs.compute_affinity_huber_loss(pred, None, torch.from_numpy(z["target"]).to(DEV), [1.5, 0.5])
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    e = rel(pred.grad, z["grad_pred"])
+    assert e <= TOL, "grad %.2e" % e

@@ -183,3 +183,13 @@ def test_depth_metrics_match_reference_fixture(name):
     total, metrics = O.depth_losses(torch.from_numpy(z["depth"]), torch.from_numpy(z["depth_gt"]))
     np.testing.assert_allclose(np.array([float(v) for v in metrics]), z["metrics"], rtol=1e-6)
     assert abs(float(total) - float(z["total"])) <= 1e-6 * abs(float(z["total"]))
+
+
+def test_affinity_huber_variant_matches_reference_fixture():
+    """Trainer_distilation.py:1076-1110 called directly on a float64 prediction: value and gradient."""
+    z = np.load(os.path.join(GOLDEN_DIR, "affinity", "huber_b2_24x80.npz"))
+    pred = torch.from_numpy(z["pred"]).double().requires_grad_(True)
+    loss = O.affinity_huber_loss(pred, torch.from_numpy(z["target"]))
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) <= 1e-12
+    np.testing.assert_allclose(pred.grad.numpy(), z["grad_pred"], rtol=0, atol=1e-15)
