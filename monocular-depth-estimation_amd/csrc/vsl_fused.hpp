@@ -283,6 +283,10 @@ VSL_DEV float lane_right(float v) {
 }
 #endif
 
+// y * W + x for y, W < 2^24 (checked on the host): the masks let the compiler pick the 24-bit multiply-add, a
+// full-rate instruction, where the 32-bit multiply runs at a quarter of that.
+VSL_DEV unsigned row_major(unsigned y, unsigned W, unsigned x) { return (y & 0xFFFFFFu) * (W & 0xFFFFFFu) + x; }
+
 struct Taps {
   int i0, i1;
   float t;
@@ -307,14 +311,38 @@ VSL_DEV Taps axis_taps(float g, int n) {
   return tp;
 }
 
+// The same for the tile program, which wants the first tap, whether a second one follows it and whether the
+// derivative passes.  The clipped coordinate is never NaN (fmax(NaN, 0) is 0) and lies in [0, n-1], so its integer
+// part needs no further clamping and truncation equals floor.
+struct TileTaps {
+  int i0;
+  float t;
+  bool step;  // the second tap is i0 + 1 (else i0 = n-1 and the second tap repeats it with weight 0)
+  bool live;
+};
+VSL_DEV TileTaps tile_taps(float g, int n) {
+  const double c = ((double)g + 1.0) * ((double)n * 0.5) - 0.5;
+  const double top = (double)(n - 1);
+  TileTaps tp;
+  tp.live = c > 0.0 && c < top;
+  const double cc = fmin(fmax(c, 0.0), top);
+  tp.i0 = (int)cc;
+#if defined(__HIP_DEVICE_COMPILE__)
+  tp.t = (float)__builtin_amdgcn_fract(cc);  // cc - floor(cc) is exact, and so is the fraction instruction
+#else
+  tp.t = (float)(cc - floor(cc));
+#endif
+  tp.step = tp.i0 < n - 1;
+  return tp;
+}
+
 // What phase 3 needs from phase 1 for one (pixel, source): where the four bilinear taps are and
 // their fractions.  Three registers instead of the six tap derivatives; phase 3 fetches the taps
 // again (they are cache hits) and rebuilds the derivatives.
 struct Chain {
-  float tx, ty;  // bilinear fractions
+  float tx, ty;  // bilinear fractions; tx is relative to the texel pair below (1 when x0 = W-1)
   int packed;    // bits 0..27 offset of texel (y0, min(x0, W-2)) in the image plane: the 8 bytes there hold both
-                 // x taps; 28: x1 = x0+1 (else x0 = W-1 and both taps are the second texel), 29: y1 = y0+1,
-                 // 30: d/dx passes (0 < ix < W-1), 31: d/dy passes
+                 // x taps; 29: y1 = y0+1, 30: d/dx passes (0 < ix < W-1), 31: d/dy passes
 };
 
 // Projection matrices P = (K T)[:3,:] of every source and the 3x3 part of inv_K: the same for every thread of a
@@ -511,7 +539,7 @@ struct Ident {
     // Tiles whose grown region lies inside the image horizontally (all but the first and last of a row) need no
     // reflection in x: the two pixels of a pair are neighbours in memory and come from one 8-byte load per plane.
     if (bk.x0 >= 1 && bk.x0 + TW + 1 <= kp.W) {
-      const unsigned off = ((unsigned)py * (unsigned)kp.W + (unsigned)(bk.x0 - 1 + rx0)) << 2;
+      const unsigned off = row_major((unsigned)py, (unsigned)kp.W, (unsigned)(bk.x0 - 1 + rx0)) << 2;
       float* row = lds + ry * RW + rx0;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -528,7 +556,7 @@ struct Ident {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int px = reflect_clamp(bk.x0 - 1 + rx0 + k, kp.W);
-      const unsigned pix = (unsigned)py * (unsigned)kp.W + (unsigned)px;
+      const unsigned pix = row_major((unsigned)py, (unsigned)kp.W, (unsigned)px);
       const int p = ry * RW + rx0 + k;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -686,7 +714,7 @@ struct Fused {
     for (int k = 0; k < 2; ++k) {
       const int px = reflect_clamp(bk.x0 - HALO + rx0 + k, W);
       const int p2 = ry * R2W + rx0 + k;
-      const unsigned pix = (unsigned)py * (unsigned)W + (unsigned)px;
+      const unsigned pix = row_major((unsigned)py, (unsigned)W, (unsigned)px);
       const float d = load_f32_at(dispb, pix << 2);
       lds[OFF_DSP + p2] = d;
 #pragma unroll
@@ -722,27 +750,28 @@ struct Fused {
         const float u = quot(cam[0], by_den), v = quot(cam[1], by_den);
         const float gx = VSL_FMUL(VSL_FSUB(quot(u, by_wm1), 0.5f), 2.0f);
         const float gy = VSL_FMUL(VSL_FSUB(quot(v, by_hm1), 0.5f), 2.0f);
-        const Taps tx = axis_taps(gx, W), ty = axis_taps(gy, H);
+        const TileTaps tx = tile_taps(gx, W), ty = tile_taps(gy, H);
         const float* sp = src_image(kp, s) + (size_t)bk.b * 3 * HW;
         // both x taps of a row come from one 8-byte load at min(x0, W-2)
-        const bool xs = tx.i1 != tx.i0, ys = ty.i1 != ty.i0;
-        const unsigned o0 = (unsigned)ty.i0 * (unsigned)W + (unsigned)(xs ? tx.i0 : W - 2);
+        const bool xs = tx.step, ys = ty.step;
+        const unsigned o0 = row_major((unsigned)ty.i0, (unsigned)W, (unsigned)(tx.i0 < W - 2 ? tx.i0 : W - 2));
         const unsigned o1 = o0 + (ys ? (unsigned)W : 0u);
-        const float w00 = (1.0f - tx.t) * (1.0f - ty.t), w01 = tx.t * (1.0f - ty.t);
-        const float w10 = (1.0f - tx.t) * ty.t, w11 = tx.t * ty.t;
+        // At the last column (x0 = W-1, fraction 0) the pair holds texels W-2 and W-1: fraction 1 on that pair is
+        // the same sample, weight for weight, and needs no selection between the two halves.
+        const float txe = xs ? tx.t : 1.0f;
+        const float w00 = (1.0f - txe) * (1.0f - ty.t), w01 = txe * (1.0f - ty.t);
+        const float w10 = (1.0f - txe) * ty.t, w11 = txe * ty.t;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float* pc = sp + (size_t)c * HW;
           const TexelPair a = load_texel_pair_at(pc, o0 << 2), b = load_texel_pair_at(pc, o1 << 2);
-          const float v00 = xs ? a.lo : a.hi, v01 = a.hi;
-          const float v10 = xs ? b.lo : b.hi, v11 = b.hi;
-          lds[OFF_WRP + (s * 3 + c) * P2 + p2] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+          lds[OFF_WRP + (s * 3 + c) * P2 + p2] = a.lo * w00 + a.hi * w01 + b.lo * w10 + b.hi * w11;
         }
         Chain& ch = st.ch[k][s];
-        ch.tx = tx.t;
+        ch.tx = txe;
         ch.ty = ty.t;
-        ch.packed = (int)(o0 | ((unsigned)xs << 28) | ((unsigned)ys << 29) | ((unsigned)(tx.live != 0.0f) << 30) |
-                          ((unsigned)(ty.live != 0.0f) << 31));
+        ch.packed = (int)(o0 | ((unsigned)ys << 29) | ((unsigned)tx.live << 30) |
+                          ((unsigned)ty.live << 31));
         if (HALO == 2 && ry >= TH && ry < TH + 2) {
           float* xf = lds + OFF_XFER + (((ry - TH) * ROWP + tid % ROWP) * 2 + k) * (S * 3) + s * 3;
           xf[0] = ch.tx;
@@ -784,7 +813,7 @@ struct Fused {
     if (kp.automask) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
-        if (valid[k]) best[k] = load_f32_at(kp.idmin + (size_t)bk.b * HW, ((unsigned)gy * (unsigned)kp.W + (unsigned)(gx0 + k)) << 2);
+        if (valid[k]) best[k] = load_f32_at(kp.idmin + (size_t)bk.b * HW, row_major((unsigned)gy, (unsigned)kp.W, (unsigned)(gx0 + k)) << 2);
     }
     float win[2] = {-1.0f, -1.0f};
     float rsum[2] = {0.0f, 0.0f};
@@ -931,7 +960,7 @@ struct Fused {
       if (interior[k]) {
         st.photo += best[k];
         if (kp.automask && hv.ident_sel)
-          store_f32_at(hv.ident_sel + (size_t)bk.b * HW, ((unsigned)gy * (unsigned)kp.W + (unsigned)(gx0 + k)) << 2,
+          store_f32_at(hv.ident_sel + (size_t)bk.b * HW, row_major((unsigned)gy, (unsigned)kp.W, (unsigned)(gx0 + k)) << 2,
                        (win[k] >= 0.0f) ? 1.0f : 0.0f);
       }
     }
@@ -1113,15 +1142,14 @@ struct Fused {
         for (int k = 0; k < 2; ++k) {
           const unsigned pk = (unsigned)chn[k][s].packed;
           const unsigned o0 = pk & 0x0FFFFFFFu;
-          const bool xs = (pk >> 28) & 1u;
           const unsigned o1 = o0 + (((pk >> 29) & 1u) ? (unsigned)W : 0u);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float* pc = src_image(kp, s) + ((size_t)bk.b * 3 + c) * HW;
             const TexelPair a = load_texel_pair_at(pc, o0 << 2), b = load_texel_pair_at(pc, o1 << 2);
-            tv[k][c][0] = xs ? a.lo : a.hi;
+            tv[k][c][0] = a.lo;
             tv[k][c][1] = a.hi;
-            tv[k][c][2] = xs ? b.lo : b.hi;
+            tv[k][c][2] = b.lo;
             tv[k][c][3] = b.hi;
           }
         }
@@ -1185,7 +1213,7 @@ struct Fused {
     if (hv.want_grad) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
-        if (ok[k]) store_f32_at(hv.gphoto + (size_t)bk.b * HW, ((unsigned)jy * (unsigned)W + (unsigned)(jx0 + k)) << 2, g_disp[k]);
+        if (ok[k]) store_f32_at(hv.gphoto + (size_t)bk.b * HW, row_major((unsigned)jy, (unsigned)W, (unsigned)(jx0 + k)) << 2, g_disp[k]);
     }
   }
 
@@ -1238,7 +1266,7 @@ struct Fused {
         if (t == 2) st.part[3] = fmaf(w, fabsf(diff), st.part[3]);
       }
       st.part[1] += d0;
-      if (hv.want_grad) store_f32_at(hv.gedge + (size_t)bk.b * HW, ((unsigned)jy * (unsigned)W + (unsigned)jx) << 2, e);
+      if (hv.want_grad) store_f32_at(hv.gedge + (size_t)bk.b * HW, row_major((unsigned)jy, (unsigned)W, (unsigned)jx) << 2, e);
     }
   }
 

@@ -431,7 +431,8 @@ int check_desc(const vsl_loss_desc* d) {
   if (d->B > 65535) return fail(VSL_ERR_INVALID_ARGUMENT, "B exceeds 65535");
   if ((long long)d->B * d->H * d->W * 3 >= (1ll << 31))
     return fail(VSL_ERR_INVALID_ARGUMENT, "B*3*H*W must stay below 2^31");
-  if ((long long)d->H * d->W >= (1ll << 28)) return fail(VSL_ERR_INVALID_ARGUMENT, "H*W must stay below 2^28");
+  if ((long long)d->H * d->W >= (1ll << 28) || d->H >= (1 << 24) || d->W >= (1 << 24))
+    return fail(VSL_ERR_INVALID_ARGUMENT, "H*W must stay below 2^28 and H, W below 2^24");
   if (d->S < 1 || d->S > VSL_MAX_SOURCES) return fail(VSL_ERR_INVALID_ARGUMENT, "S must be 1..VSL_MAX_SOURCES");
   if (!(d->min_depth > 0.0f) || !(d->max_depth > d->min_depth))
     return fail(VSL_ERR_INVALID_ARGUMENT, "need 0 < min_depth < max_depth");
