@@ -75,7 +75,9 @@ class LossStep:
             d.K, d.inv_K = t["K"].data_ptr(), t["inv_K"].data_ptr()
             d.noise = None          # in-kernel counter-based tie-break noise
             d.seed = 1234
-            d.identity_min = self.idmin.data_ptr() if automask else None
+            # merged launch: the identity pass runs inside vsl_loss_forward_heads (once for all heads); per-head
+            # calls share one explicit vsl_identity_min result instead
+            d.identity_min = self.idmin.data_ptr() if (automask and not merged) else None
             n = abi.lib.vsl_loss_workspace_bytes(ctypes.byref(d))
             self.descs.append(d)
             self.ws.append(torch.empty(n, dtype=torch.uint8, device=dev))
@@ -100,13 +102,16 @@ class LossStep:
         """Per-head calls only: run the heads on n side streams (they are independent once the identity
         minimum exists)."""
         self.merged = False
+        if self.idmin is not None:
+            for d in self.descs:
+                d.identity_min = self.idmin.data_ptr()
         self.side = [torch.cuda.Stream(device=self.dev) for _ in range(n)]
         self.ev_fork = torch.cuda.Event()
         self.ev_join = [torch.cuda.Event() for _ in range(n)]
 
     def __call__(self, stream, stream_obj=None):
         abi = self.abi
-        if self.idmin is not None:
+        if self.idmin is not None and not self.merged:
             abi.check(abi.lib.vsl_identity_min(ctypes.byref(self.descs[0]), self.idmin.data_ptr(), stream))
         if self.merged:
             abi.check(abi.lib.vsl_loss_forward_heads(ctypes.byref(self.descs[0]), self.heads, self.n_heads, stream))
