@@ -194,15 +194,36 @@ VSL_DEV float sgn(float v) {
 #endif
 }
 
-// splitmix64-style hash -> N(0,1); used when the caller passes no noise tensor
-VSL_DEV float hash_normal(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+// Tie-break noise when the caller passes no noise tensor: a counter-based generator, N(0,1) per (seed, plane,
+// pixel).  The part that depends on the seed and the plane (image x source) is uniform over a workgroup and runs
+// on the scalar unit (splitmix64 finaliser); per pixel a 32-bit mixer (two multiplies) gives 24 bits for the radius
+// and, after one more multiply, 24 bits for the angle of a Box-Muller transform.  On the device the logarithm,
+// square root and cosine are the hardware's approximations (the cosine instruction takes revolutions): the values
+// only separate candidates that are equal to within 1e-5, so a few ulp do not matter; the cost does, this runs
+// once per pixel and source.
+VSL_DEV unsigned long long noise_key(unsigned long long seed, unsigned plane) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)plane + 1);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  float u1 = ((float)((z >> 40) & 0xFFFFFF) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
-  float u2 = (float)((z >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  return z ^ (z >> 31);
+}
+VSL_DEV float hash_normal(unsigned long long key, unsigned pix) {
+  unsigned x = pix ^ (unsigned)key;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  x += (unsigned)(key >> 32);
+  const unsigned y = x * 0x9E3779B1u;
+  const float u1 = ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+  const float u2 = (float)(y >> 8) * (1.0f / 16777216.0f);           // [0,1)
+#if defined(__HIP_DEVICE_COMPILE__)
+  // -2 ln(u1) = -2 ln(2) log2(u1)
+  return __builtin_amdgcn_sqrtf(-1.38629436112f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+#else
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
+#endif
 }
 
 // Projection matrix P = (K @ T)[:3,:] with separate multiply and add roundings
@@ -611,15 +632,14 @@ struct Ident {
         if (AVG) {
           idsum += e;
         } else {
-          const size_t ni = ((size_t)bk.b * NI + s) * HW + pix;
-          const float z = kp.noise ? kp.noise[ni] : hash_normal(kp.seed, ni);
+          const unsigned plane = (unsigned)(bk.b * NI + s);
+          const float z = kp.noise ? kp.noise[(size_t)plane * HW + pix] : hash_normal(noise_key(kp.seed, plane), (unsigned)pix);
           const float v = fmaf(z, 0.00001f, e);
           if (v < best) best = v;
         }
       }
       if (AVG) {
-        const size_t ni = (size_t)bk.b * HW + pix;
-        const float z = kp.noise ? kp.noise[ni] : hash_normal(kp.seed, ni);
+        const float z = kp.noise ? kp.noise[(size_t)bk.b * HW + pix] : hash_normal(noise_key(kp.seed, (unsigned)bk.b), (unsigned)pix);
         best = fmaf(z, 0.00001f, idsum * (1.0f / S));
       }
       kp.idmin[(size_t)bk.b * HW + pix] = best;
