@@ -243,22 +243,23 @@ __global__ __launch_bounds__(1024) void vsl_finalize_kernel(const FinalizeParams
   const int tid = threadIdx.x;
   const int v = tid & 63, r = tid >> 6;  // value index, row group (16 tile records in flight per step)
   const int npart = num_partials(fp.S);
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (v < npart) {
     const float* base = fh.partials + (size_t)b * fp.tiles_per_image * kPartStride + v;
     const int n = fp.tiles_per_image;
     int t = r;
-    for (; t + 48 < n; t += 64) {  // four independent loads per step, fixed association order
-      const float x0 = base[(size_t)t * kPartStride], x1 = base[(size_t)(t + 16) * kPartStride];
-      const float x2 = base[(size_t)(t + 32) * kPartStride], x3 = base[(size_t)(t + 48) * kPartStride];
-      a0 += (double)x0;
-      a1 += (double)x1;
-      a2 += (double)x2;
-      a3 += (double)x3;
+    for (; t + 112 < n; t += 128) {  // eight independent loads per step (the loop is latency bound), fixed association order
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = base[(size_t)(t + 16 * i) * kPartStride];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += (double)x[i];
     }
-    for (; t < n; t += 16) a0 += (double)base[(size_t)t * kPartStride];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)  // at most eight records are left
+      if (t + 16 * i < n) acc[i] += (double)base[(size_t)(t + 16 * i) * kPartStride];
   }
-  red[r][v] = (a0 + a1) + (a2 + a3);
+  red[r][v] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
   if (tid < 64) {
     double s = 0.0;
