@@ -678,12 +678,7 @@ struct Fused {
   static constexpr int NRED = HALO == 2 ? NPART : 4;  // partial sums that can be non-zero
   static constexpr int RED_FLOATS = NRED * RED_PITCH;
   static constexpr int RED_SPLIT = 8;
-  // Tap records of the last two interior rows, handed from the threads that warped them (R2 rows TH, TH+1) to
-  // the threads of R2 rows 0, 1: phase 3 then keeps the last wave (R2 rows TH..TH+3) completely idle instead of
-  // running four half-empty waves.
-  static constexpr int OFF_XFER = OFF_COEF + COEF_FLOATS;
-  static constexpr int XFER_FLOATS = HALO == 2 ? 2 * ROWP * 2 * S * 3 : 0;
-  static constexpr int LDS_MAIN = OFF_XFER + XFER_FLOATS;
+  static constexpr int LDS_MAIN = OFF_COEF + COEF_FLOATS;
   static constexpr int RED_TOTAL = RED_FLOATS + NRED * RED_SPLIT;
   static constexpr int LDS_FLOATS = LDS_MAIN > RED_TOTAL ? LDS_MAIN : RED_TOTAL;
 
@@ -718,8 +713,12 @@ struct Fused {
   // pair is interior use that again in phase 3.
   static VSL_DEV void phase1(const KParams& kp, const HeadView& hv, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
     st.photo = 0.0f;
-    const int ry = tid / ROWP, rx0 = 2 * (tid % ROWP);
-    if (ry >= R2H || rx0 >= R2W) return;
+    const int trow = tid / ROWP, rx0 = 2 * (tid % ROWP);
+    if (trow >= R2H || rx0 >= R2W) return;
+    // Full program: thread row t warps R2 row t + 2 (wrapping round), so that thread rows 0..TH-1 -- whole waves --
+    // hold the tap records of the interior rows, which the same threads differentiate in phase 3, and the halo
+    // rows fall to the last wave, which phase 3 gives the smoothness term instead.
+    const int ry = HALO == 2 ? (trow + 2 < R2H ? trow + 2 : trow + 2 - R2H) : trow;
     const int H = kp.H, W = kp.W;
     const unsigned HW = (unsigned)H * (unsigned)W;
     // per-image bases are uniform over the workgroup; per-lane offsets stay unsigned 32-bit
@@ -792,12 +791,6 @@ struct Fused {
         ch.ty = ty.t;
         ch.packed = (int)(o0 | ((unsigned)ys << 29) | ((unsigned)tx.live << 30) |
                           ((unsigned)ty.live << 31));
-        if (HALO == 2 && ry >= TH && ry < TH + 2) {
-          float* xf = lds + OFF_XFER + (((ry - TH) * ROWP + tid % ROWP) * 2 + k) * (S * 3) + s * 3;
-          xf[0] = ch.tx;
-          xf[1] = ch.ty;
-          xf[2] = __builtin_bit_cast(float, ch.packed);
-        }
       }
     }
   }
@@ -992,15 +985,14 @@ struct Fused {
     for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
     st.part[0] = st.photo;
     const int H = kp.H, W = kp.W;
-    // (R2 row, R2 pair) of phase 1 -> interior coordinates; the threads of R2 rows 0, 1 (halo in phase 1) take
-    // over the last two interior rows, so that the R2 rows from TH on -- the whole last wave -- stay idle
+    // thread row t warped R2 row t + 2 in phase 1, the interior row t; rows from TH on -- the whole last wave --
+    // held halo rows only
     const int row = tid / ROWP, ip = tid % ROWP - 1;
     if (row >= TH) {
       phase3_smooth(kp, hv, bk, tid, lds, st);
       return;
     }
-    const bool remote = row < 2;
-    const int iy = remote ? row + TH - 2 : row - 2;
+    const int iy = row;
     // one combined test (no short-circuit): nested early exits make the compiler re-zero all partial sums at every level
     const bool off_tile = (unsigned)ip >= (unsigned)(TW / 2);  // covers ip < 0 as well
     const bool off_image = bk.y0 + iy >= kp.H;
@@ -1017,12 +1009,6 @@ struct Fused {
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         chn[k][s] = st.ch[k][s];
-        if (remote) {
-          const float* xf = lds + OFF_XFER + ((row * ROWP + tid % ROWP) * 2 + k) * (S * 3) + s * 3;
-          chn[k][s].tx = xf[0];
-          chn[k][s].ty = xf[1];
-          chn[k][s].packed = __builtin_bit_cast(int, xf[2]);
-        }
       }
     const int jy = bk.y0 + iy;
     const int jx0 = bk.x0 + 2 * ip;

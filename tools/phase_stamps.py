@@ -17,7 +17,7 @@ stream = torch.cuda.current_stream().cuda_stream
 for _ in range(5):
     step(stream)
 torch.cuda.synchronize()
-TH = int(os.environ.get('VSL_TILE_H', '28')); NW = (TH + 4) // 4
+TH = int(os.environ.get('VSL_TILE_H', '12')); NW = (TH + 4) // 4
 blocks = ((W + 27) // 28) * ((H + TH - 1) // TH) * B
 buf = np.zeros((blocks, 8, 16), np.uint64)      # the library reserves 8 wave slots per workgroup
 abi.lib.vsl_debug_read_stamps.restype = ctypes.c_longlong
