@@ -42,6 +42,12 @@ def test_argument_validation_without_gpu():
     assert abi.lib.vsl_loss_forward(ctypes.byref(d), None, 0, None, None, None) == -1
     d.S, d.n_scales, d.min_depth, d.max_depth = 1, 1, 0.1, 100.0
     assert abi.lib.vsl_loss_forward(ctypes.byref(d), None, 0, None, None, None) == -1   # NULL tensors
+    d.H, d.W = 2, 1 << 24                      # a row index times W must fit the 24-bit multiply of the kernels
+    rc = abi.lib.vsl_loss_forward(ctypes.byref(d), None, 0, None, None, None)
+    assert rc == -1 and b"2^24" in abi.lib.vsl_last_error_string()
+    d.H, d.W = 1 << 14, 1 << 14                # H*W = 2^28: offsets within a plane no longer fit 28 bits
+    rc = abi.lib.vsl_loss_forward(ctypes.byref(d), None, 0, None, None, None)
+    assert rc == -1 and b"2^28" in abi.lib.vsl_last_error_string()
     with pytest.raises(abi.VslError):
         abi.check(-1)
 
