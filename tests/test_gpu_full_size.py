@@ -357,3 +357,30 @@ def test_in_kernel_tie_break_noise_is_standard_normal_and_keyed_by_seed():
     for a, b in ((z[:, :, 1:], z[:, :, :-1]), (z[:, 1:], z[:, :-1]), (z[1:], z[:-1]), (z, z_other)):
         c = float((a * b).mean())
         assert abs(c) < 5.0 / a.numel() ** 0.5, c
+
+
+def test_directional_derivative_agrees_with_the_gradient_at_benchmark_size():
+    """Oracle-free check of forward against backward at 640x192 b12: along v = sign(grad_disp) the central
+    difference (L(d + e v) - L(d - e v)) / 2e must equal sum |grad_disp|.  The loss has kinks (|.|, the per-pixel
+    minimum, the SSIM clamp) and is evaluated in float32, so the agreement is a few parts in a thousand; a wrong
+    backward term (a missing factor, a sign, a dropped halo contribution) would show at the percent level or more."""
+    import mde_amd._abi as abi
+    import mde_amd.synth as synth
+    from mde_amd.ops import fused_view_synthesis_loss
+    B, H, W, fids = 12, 192, 640, [0, -1, 1]
+    data = synth.make_batch(B, H, W, fids, seed=23)
+    img = lambda f: data[("image", f)].to(DEV)
+    args = (img(0), [img(f) for f in fids[1:]], data["K"].to(DEV), data["inv_K"].to(DEV),
+            [data[("cam_T_cam", f)].to(DEV) for f in fids[1:]], data["noise"].to(DEV))
+    d = data[("disp", 0)].to(DEV).requires_grad_(True)
+    out, _ = fused_view_synthesis_loss(d, *args, scale_weights=[1e-3])
+    out[abi.LOSS_TOTAL].backward()
+    v = torch.sign(d.grad)
+    expect = float(d.grad.double().abs().sum())
+    eps = 1e-4
+    with torch.no_grad():
+        lp = float(fused_view_synthesis_loss(d.detach() + eps * v, *args, scale_weights=[1e-3])[0][abi.LOSS_TOTAL])
+        lm = float(fused_view_synthesis_loss(d.detach() - eps * v, *args, scale_weights=[1e-3])[0][abi.LOSS_TOTAL])
+    got = (lp - lm) / (2 * eps)
+    print("directional derivative %.6e, sum |grad| %.6e, ratio %.5f" % (got, expect, got / expect))
+    assert abs(got / expect - 1.0) < 0.02
