@@ -384,3 +384,28 @@ def test_directional_derivative_agrees_with_the_gradient_at_benchmark_size():
     got = (lp - lm) / (2 * eps)
     print("directional derivative %.6e, sum |grad| %.6e, ratio %.5f" % (got, expect, got / expect))
     assert abs(got / expect - 1.0) < 0.02
+
+
+def test_directional_derivative_agrees_with_the_pose_gradient_at_benchmark_size():
+    """The same check for the pose matrices (the 12 entries of [R|t] of every image and source, perturbed as free
+    variables along the sign of their gradient): central difference against sum |grad_T|."""
+    import mde_amd._abi as abi
+    import mde_amd.synth as synth
+    from mde_amd.ops import fused_view_synthesis_loss
+    B, H, W, fids = 12, 192, 640, [0, -1, 1]
+    data = synth.make_batch(B, H, W, fids, seed=29)
+    img = lambda f: data[("image", f)].to(DEV)
+    d = data[("disp", 0)].to(DEV)
+    poses = [data[("cam_T_cam", f)].to(DEV).requires_grad_(True) for f in fids[1:]]
+    run = lambda ps: fused_view_synthesis_loss(d, img(0), [img(f) for f in fids[1:]], data["K"].to(DEV), data["inv_K"].to(DEV),
+                                               ps, data["noise"].to(DEV), scale_weights=[1e-3])[0][abi.LOSS_TOTAL]
+    run(poses).backward()
+    vs = [torch.sign(p.grad) for p in poses]
+    expect = sum(float(p.grad.double().abs().sum()) for p in poses)
+    eps = 5e-6
+    with torch.no_grad():
+        lp = float(run([p.detach() + eps * v for p, v in zip(poses, vs)]))
+        lm = float(run([p.detach() - eps * v for p, v in zip(poses, vs)]))
+    got = (lp - lm) / (2 * eps)
+    print("directional derivative %.6e, sum |grad_T| %.6e, ratio %.5f" % (got, expect, got / expect))
+    assert abs(got / expect - 1.0) < 0.02
