@@ -1012,7 +1012,10 @@ struct Fused {
       }
     const int jy = bk.y0 + iy;
     const int jx0 = bk.x0 + 2 * ip;
-    const bool ok[2] = {true, jx0 + 1 < W};
+    // pairs kept alive for the lane exchange below take part in the rest as pixels that do not exist: no
+    // contribution to any sum, no store (an early exit for them after the exchange made the compiler zero all partial
+    // sums once more on that path)
+    const bool ok[2] = {!inactive, !inactive && jx0 + 1 < W};
     const float* coef = lds + OFF_COEF;
     const float* sel = lds + OFF_COEF + NSET * 9 * P1;
     const int qb = iy * R1W + 2 * ip;  // R1 offset of the window's top-left (even)
@@ -1127,9 +1130,6 @@ struct Fused {
           VSL_SCHED_FENCE();
         }
       }
-#if defined(__HIPCC__)
-      if (inactive) return;
-#endif
 
       float D[2], r[2][3];
 #pragma unroll
