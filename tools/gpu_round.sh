@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/r01
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="--steps 50 --warmup 5 --no-cpu-baseline"
+B="--steps 200 --warmup 20 --no-cpu-baseline"
 timeout -k 10 420 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $OUT/pytest_gpu.log 2>&1 \
  && tail -3 $OUT/pytest_gpu.log \
  && timeout -k 10 120 python -u -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1 \
