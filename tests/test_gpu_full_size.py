@@ -409,3 +409,27 @@ def test_directional_derivative_agrees_with_the_pose_gradient_at_benchmark_size(
     got = (lp - lm) / (2 * eps)
     print("directional derivative %.6e, sum |grad_T| %.6e, ratio %.5f" % (got, expect, got / expect))
     assert abs(got / expect - 1.0) < 0.02
+
+
+def test_a_step_captured_in_a_hip_graph_replays_bit_for_bit():
+    """The entry points allocate nothing and only enqueue work on the caller's stream, so a whole step (identity
+    pass, fused kernel, finalize, gradient assembly of two heads) can be captured in a HIP graph
+    (torch.cuda.CUDAGraph) and replayed: every output equals the eager calls bit for bit."""
+    import bench
+    B, H, W, fids, heads = 2, 192, 640, [0, -1, 1], 2
+    dev = torch.device(DEV)
+    data, t = bench.build_inputs(B, H, W, fids, heads, dev)
+    step = bench.LossStep(t, B, H, W, fids, heads, dev)
+    outputs = lambda: step.losses + step.gdisp + [g for gs in step.gT for g in gs] + step.ident
+    step(torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    eager = [x.clone() for x in outputs()]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=torch.cuda.Stream(dev)):
+        step(torch.cuda.current_stream(dev).cuda_stream)
+    for x in outputs():
+        x.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, outputs()):
+        assert torch.equal(a, b)
