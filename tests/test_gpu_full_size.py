@@ -433,3 +433,43 @@ def test_a_step_captured_in_a_hip_graph_replays_bit_for_bit():
     torch.cuda.synchronize()
     for a, b in zip(eager, outputs()):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("fids,flags", [
+    ([0, 1], {}),
+    ([0, -1, 1, "s"], {}),
+    ([0, -1, 1], {"avg_reprojection": True}),
+    ([0, -1, 1, "s"], {"avg_reprojection": True}),
+    ([0, -1, 1], {"no_ssim": True}),
+    ([0, -1, 1], {"automask": False}),
+])
+def test_directional_derivative_of_the_other_kernel_variants(fids, flags):
+    """Forward against backward without the oracle for the other instantiations of the tile program (one and
+    three sources, averaged reprojection, L1 only, no auto-masking), 4 x 192 x 640: disparity and pose directions
+    together, central difference against sum |grad|."""
+    import mde_amd._abi as abi
+    import mde_amd.synth as synth
+    from mde_amd.ops import fused_view_synthesis_loss
+    B, H, W = 4, 192, 640
+    data = synth.make_batch(B, H, W, fids, seed=31 + len(fids))
+    img = lambda f: data[("image", f)].to(DEV)
+    pose = lambda f: (data["stereo_T"] if f == "s" else data[("cam_T_cam", f)]).to(DEV)
+    S = len(fids) - 1
+    noise = data["noise"].to(DEV)
+    if flags.get("avg_reprojection"):
+        noise = noise[:, :1].contiguous()
+    run = lambda d, ps: fused_view_synthesis_loss(d, img(0), [img(f) for f in fids[1:]], data["K"].to(DEV), data["inv_K"].to(DEV),
+                                                  ps, noise, scale_weights=[1e-3], **flags)[0][abi.LOSS_TOTAL]
+    d = data[("disp", 0)].to(DEV).requires_grad_(True)
+    poses = [pose(f).requires_grad_(True) for f in fids[1:]]
+    run(d, poses).backward()
+    for what, eps in (("disp", 1e-4), ("pose", 5e-6)):
+        vd = torch.sign(d.grad) if what == "disp" else torch.zeros_like(d)
+        vp = [torch.sign(p.grad) if what == "pose" else torch.zeros_like(p) for p in poses]
+        expect = float(d.grad.double().abs().sum()) if what == "disp" else sum(float(p.grad.double().abs().sum()) for p in poses)
+        with torch.no_grad():
+            lp = float(run(d.detach() + eps * vd, [p.detach() + eps * v for p, v in zip(poses, vp)]))
+            lm = float(run(d.detach() - eps * vd, [p.detach() - eps * v for p, v in zip(poses, vp)]))
+        got = (lp - lm) / (2 * eps)
+        print("%s %s: directional derivative %.6e, sum |grad| %.6e, ratio %.5f" % (fids, what, got, expect, got / expect))
+        assert abs(got / expect - 1.0) < 0.03, (what, got / expect)
