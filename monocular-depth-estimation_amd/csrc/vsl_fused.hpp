@@ -830,12 +830,11 @@ struct Fused {
     }
     float win[2] = {-1.0f, -1.0f};
     float rsum[2] = {0.0f, 0.0f};
-    // (!AVG) the winner's nine coefficients of both pixels stay in registers and go to LDS once, as pairs
+    // (!AVG) the winner's nine coefficients of both pixels stay in registers and go to LDS once, as pairs.  Where no
+    // source wins (identity term smaller, or a position outside the image) the planes hold the first source's
+    // coefficients: finite values that phase 3 multiplies by a zero mask, since the selection plane says -1 there --
+    // so the first source needs no selection and nothing has to be cleared.
     float wc[2][9];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int j = 0; j < 9; ++j) wc[k][j] = 0.0f;
     if constexpr (S <= 3) {
       // Channel by channel: the target window, its differences to the centre and its statistics are formed once and
       // serve every source frame; the per-source sums over the channels keep their order (c ascending).
@@ -889,7 +888,7 @@ struct Fused {
             best[k] = take ? e : best[k];
             win[k] = take ? (float)s : win[k];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) wc[k][j] = take ? cf[s][k][j] : wc[k][j];
+            for (int j = 0; j < 9; ++j) wc[k][j] = (s == 0 || take) ? cf[s][k][j] : wc[k][j];
           }
         }
       }
@@ -951,7 +950,7 @@ struct Fused {
             best[k] = take ? e : best[k];
             win[k] = take ? (float)s : win[k];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) wc[k][j] = take ? cf[k][j] : wc[k][j];
+            for (int j = 0; j < 9; ++j) wc[k][j] = (s == 0 || take) ? cf[k][j] : wc[k][j];
           }
         }
       }
