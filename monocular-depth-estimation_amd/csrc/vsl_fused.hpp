@@ -1121,11 +1121,26 @@ struct Fused {
               }
             }
           }
+          if constexpr (AVG) {
 #pragma unroll
-          for (int s = 0; s < S; ++s)
+            for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-              g[s][k][c] = hv.cst_ssim * gs[s][k] - hv.cst_l1 * mf[AVG ? 0 : s][1][1 + k - J0] * sgn(yv[k] - xv[s][k]);
+              for (int k = 0; k < 2; ++k)
+                g[s][k][c] = hv.cst_ssim * gs[s][k] - hv.cst_l1 * mf[0][1][1 + k - J0] * sgn(yv[k] - xv[s][k]);
+          } else {
+            // At most one source wins a pixel, and only the winner's L1 term is non-zero: one sign per pixel and
+            // channel, of the difference to the winner (to source 0 where nobody wins, times a zero mask), instead
+            // of one per source.  Same values: the masked products are exact.
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              float xw = xv[0][k];
+#pragma unroll
+              for (int s = 1; s < S; ++s) xw = mf[s][1][1 + k - J0] != 0.0f ? xv[s][k] : xw;
+              const float sg = sgn(yv[k] - xw);
+#pragma unroll
+              for (int s = 0; s < S; ++s) g[s][k][c] = fmaf(hv.cst_ssim, gs[s][k], -((hv.cst_l1 * mf[s][1][1 + k - J0]) * sg));
+            }
+          }
           VSL_SCHED_FENCE();
         }
       }
