@@ -209,6 +209,20 @@ typedef struct vsl_head {
 } vsl_head;
 
 int vsl_loss_forward_heads(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, void* stream);
+/*
+ * vsl_loss_forward for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight validation / serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Forward only (as if VSL_FLAG_NO_GRAD were set; there is no matching backward): the
+ * work area is a VSL_STATIC_SCRATCH_BYTES array that the library itself holds in device memory, on
+ * every GPU it runs on, until the process ends.  The call allocates and frees nothing.  Shapes
+ * whose work area, vsl_loss_workspace_bytes(desc), exceeds VSL_STATIC_SCRATCH_BYTES are rejected
+ * with VSL_ERR_WORKSPACE_TOO_SMALL (640 x 192 with batch 2 fits).  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (different streams or threads) race; calls on one
+ * stream, or ordered by events, are safe.  Results equal vsl_loss_forward's bit for bit.
+ */
+#define VSL_STATIC_SCRATCH_BYTES (4u << 20)
+int vsl_loss_forward_static(const vsl_loss_desc* desc, float* losses, float* identity_selection, void* stream);
+
 int vsl_loss_backward_heads(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, void* stream);
 
 /* Diagnostic / benchmarking: runs vsl_loss_forward_heads `reps` times and returns in *avg_ms (host) the

@@ -19,9 +19,10 @@ FLAG_AUTOMASK, FLAG_AVG_REPROJECTION, FLAG_NO_SSIM, FLAG_NO_GRAD = 1, 2, 4, 8
 HEAD_NO_GRAD = 1
 LOSS_TOTAL, LOSS_PHOTO, LOSS_SMOOTH, LOSS_SCALE0 = 0, 1, 2, 3
 LOSS_SLOTS = 3 + MAX_SCALES
+STATIC_SCRATCH_BYTES = 4 << 20
 
 EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", "vsl_identity_min",
-           "vsl_loss_forward_heads", "vsl_loss_backward_heads",
+           "vsl_loss_forward_heads", "vsl_loss_backward_heads", "vsl_loss_forward_static",
            "vsl_disp_to_depth_fwd", "vsl_disp_to_depth_bwd", "vsl_backproject_fwd", "vsl_backproject_bwd",
            "vsl_project_fwd", "vsl_project_bwd_workspace_bytes", "vsl_project_bwd",
            "vsl_grid_sample_fwd", "vsl_grid_sample_bwd", "vsl_ssim_fwd", "vsl_ssim_bwd",
@@ -110,6 +111,8 @@ def _load():
     lib.vsl_loss_backward.argtypes = [ctypes.POINTER(LossDesc), ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.c_void_p]
+    lib.vsl_loss_forward_static.restype = ctypes.c_int
+    lib.vsl_loss_forward_static.argtypes = [ctypes.POINTER(LossDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     for name in ("vsl_loss_forward_heads", "vsl_loss_backward_heads"):
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int

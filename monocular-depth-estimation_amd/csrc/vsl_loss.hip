@@ -9,7 +9,9 @@
 //                        smoothness parts, scaled by the upstream gradient
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 
 #include "../../include/vsloss.h"
@@ -380,6 +382,40 @@ __global__ __launch_bounds__(256) void vsl_grad_kernel(const GradParams gp) {
     const int s = threadIdx.x / 16, e = threadIdx.x % 16;
     if (gh.grad_T[s]) gh.grad_T[s][b * 16 + e] = ap * gh.gT[((size_t)s * gp.B + b) * 16 + e];
   }
+}
+
+// --------------------------------------------------------------------------
+// library-owned scratch for vsl_loss_forward_static (callers that may not allocate)
+// --------------------------------------------------------------------------
+// Every GPU the library runs on holds its own copy of this array until the process ends.  In host code the
+// array's name is only a handle for hipGetSymbolAddress: the device address it returns (one per device) is what
+// kernels and memory operations get.
+constexpr size_t kStaticScratchBytes = VSL_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::atomic<void*> g_scratch_ptr[kMaxDevices];
+std::mutex g_scratch_mutex;
+
+// device address of `scratch` on the calling thread's current device (looked up once per device), or null
+void* static_scratch_ptr() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    fail(VSL_ERR_LAUNCH_FAILED, "vsl_loss_forward_static: no current device (or device index >= 64)");
+    return nullptr;
+  }
+  void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (p) return p;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  p = g_scratch_ptr[dev].load(std::memory_order_relaxed);
+  if (p) return p;
+  const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !p) {
+    fail(VSL_ERR_LAUNCH_FAILED, std::string("hipGetSymbolAddress(scratch) failed: ") + hipGetErrorString(e));
+    return nullptr;
+  }
+  g_scratch_ptr[dev].store(p, std::memory_order_release);
+  return p;
 }
 
 // --------------------------------------------------------------------------
@@ -784,6 +820,25 @@ int vsl_loss_forward(const vsl_loss_desc* d, void* workspace, size_t workspace_b
   hd.losses = losses;
   hd.identity_selection = identity_selection;
   return forward_impl(d, &hd, 1, stream_, nullptr, nullptr);
+}
+
+int vsl_loss_forward_static(const vsl_loss_desc* d, float* losses, float* identity_selection, void* stream_) {
+  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
+  if (int rc = check_desc(d)) return rc;
+  // forward only: the gradient planes would have to outlive the call in memory the caller cannot name
+  vsl_loss_desc fd = *d;
+  fd.flags |= VSL_FLAG_NO_GRAD;
+  const size_t need = make_layout(fd.B, fd.H, fd.W, desc_tile_h(&fd)).total;
+  if (need > kStaticScratchBytes)
+    return fail(VSL_ERR_WORKSPACE_TOO_SMALL,
+                "vsl_loss_forward_static: this shape needs " + std::to_string(need) + " bytes of scratch, the library holds " +
+                    std::to_string(kStaticScratchBytes) + " (VSL_STATIC_SCRATCH_BYTES); use vsl_loss_forward with a workspace");
+  void* ws = static_scratch_ptr();
+  if (!ws) return VSL_ERR_LAUNCH_FAILED;
+  vsl_head hd = head_of_desc(&fd, ws, kStaticScratchBytes);
+  hd.losses = losses;
+  hd.identity_selection = identity_selection;
+  return forward_impl(&fd, &hd, 1, stream_, nullptr, nullptr);
 }
 
 int vsl_loss_forward_heads(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, void* stream_) {
