@@ -1,13 +1,16 @@
 """Synthetic end-to-end training loop in the reference's per-batch order (Python/Trainer.py:213-243, 328-358)
 around the HIP view-synthesis loss: encoder -> depth decoder -> pose network -> pose matrices -> fused loss ->
-backward -> Adam step, one process per GPU with DistributedDataParallel (RCCL) when started under torchrun.
+backward -> Adam step, one process per GPU with ONE DistributedDataParallel wrapper (RCCL) around all networks
+when started under torchrun.
 
-The three networks below are small stand-ins with the reference's interfaces (a list of feature maps, a dict
-with ("disp", scale), (axisangle, translation) of shape [B,F,1,3]); the reference's ResNet encoder and its
-decoders are ordinary torch modules and can be passed to TrainStep instead.
+Default networks: the ResNet-18 encoder, the four-scale depth decoder and the pose decoder of
+examples/networks.py (plain torch.nn on stock PyTorch-ROCm, random initialisation); the four decoder outputs go
+to the loss as four disparity heads of one launch.  ``--tiny`` selects the three-convolution stand-ins below
+(used by the tests).  Prints one JSON line with frames/s, ms per step and the share of the step the loss
+(forward + backward of the HIP library) takes, measured with events around the loss on the same stream.
 
     python examples/synthetic_train.py --steps 20
-    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 examples/synthetic_train.py
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/synthetic_train.py
 """
 from __future__ import annotations
 
@@ -23,12 +26,13 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 class TinyEncoder(nn.Module):
-    def __init__(self, width=16):
+    def __init__(self, width=16, cin=3):
         super().__init__()
-        self.c1 = nn.Conv2d(3, width, 3, 2, 1)
+        self.c1 = nn.Conv2d(cin, width, 3, 2, 1)
         self.c2 = nn.Conv2d(width, 2 * width, 3, 2, 1)
         self.c3 = nn.Conv2d(2 * width, 4 * width, 3, 2, 1)
 
@@ -69,52 +73,57 @@ class TinyPoseDecoder(nn.Module):
         return out[..., :3], out[..., 3:]
 
 
+def build_models(opt, tiny: bool, dev):
+    if tiny:
+        return {"encoder": TinyEncoder().to(dev), "depth": TinyDepthDecoder(opt.scales).to(dev),
+                "pose": TinyPoseDecoder(len(opt.frame_ids)).to(dev)}
+    import networks as N
+    return {"encoder": N.ResNet18Encoder().to(dev), "depth": N.DepthDecoder(scales=opt.scales).to(dev),
+            "pose": N.PoseDecoder(len(opt.frame_ids), len(opt.frame_ids) - 1).to(dev)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
-    ap.add_argument("--verbose", action="store_true", help="print a line per stage and step (every rank)")
-    ap.add_argument("--share-gpu", action="store_true", help="every rank uses GPU 0 (rehearsal of the N > 1 path on one card)")
+    ap.add_argument("--tiny", action="store_true", help="three-convolution stand-in networks instead of ResNet-18")
+    ap.add_argument("--channels-last", action="store_true", help="run the networks in channels_last memory format")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap the networks in DistributedDataParallel even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", 0 if args.share_gpu else local)
+    dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
-        if args.backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=dev)
-        else:
-            torch.distributed.init_process_group(args.backend)
+    ddp = world > 1 or args.force_ddp
+    if ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        kw = {"device_id": dev} if args.backend == "nccl" else {}
+        torch.distributed.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
-    def say(msg):
-        if args.verbose:
-            print("[rank %d] %s" % (rank, msg), flush=True)
-
-    if args.verbose:      # a rank that makes no progress for 45 s prints the Python stack of every thread
-        import faulthandler
-        faulthandler.dump_traceback_later(45, repeat=False)
-    say("process group ready")
     import mde_amd.synth as synth
-    from mde_amd.trainer_step import TrainStep
+    from mde_amd.trainer_step import NetworkPass, TrainStep
 
     opt = types.SimpleNamespace(
         scales=[0, 1, 2, 3], frame_ids=[0, -1, 1], height=args.height, width=args.width, min_depth=0.1, max_depth=100.0,
         v1_multiscale=False, disable_automasking=False, avg_reprojection=False, no_ssim=False,
         disparity_smoothness=1e-3, pose_model_type="shared", pose_model_input="all", learning_rate=1e-4)
     torch.manual_seed(0)
-    models = {"encoder": TinyEncoder().to(dev), "depth": TinyDepthDecoder(opt.scales).to(dev),
-              "pose": TinyPoseDecoder(len(opt.frame_ids)).to(dev)}
-    params = [p for m in models.values() for p in m.parameters()]
-    if world > 1:
-        models = {k: nn.parallel.DistributedDataParallel(m, device_ids=[dev.index]) for k, m in models.items()}
-    say("models wrapped")
-    step = TrainStep(opt, models, torch.optim.Adam(params, opt.learning_rate))
+    net = NetworkPass(opt, build_models(opt, args.tiny, dev))
+    if args.channels_last:
+        net = net.to(memory_format=torch.channels_last)
+    params = list(net.parameters())
+    n_params = sum(p.numel() for p in params)
+    if ddp:
+        net = nn.parallel.DistributedDataParallel(net, device_ids=[dev.index])
+    # every decoder scale is a disparity head of the loss (upsampled to full resolution, Trainer.py:431)
+    step = TrainStep(opt, net, torch.optim.Adam(params, opt.learning_rate), per_scale=not args.tiny)
 
     data = synth.make_batch(args.batch, args.height, args.width, opt.frame_ids, seed=100 + rank)
     inputs = {"K": data["K"].to(dev), "inv_K": data["inv_K"].to(dev)}
@@ -122,30 +131,53 @@ def main():
         inputs[("image", f)] = data[("image", f)].to(dev)
         inputs[("image_aug", f)] = inputs[("image", f)]
 
-    first = last = None
+    # share of the loss in a step: events around the library's forward and backward calls
+    import mde_amd.ops as ops
+    marks = []
+
+    def timed(fn):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            marks.append((e0, e1))
+            return r
+        return wrapper
+
+    for cls in (ops._FusedLossFn, ops._FusedHeadsFn):
+        cls.forward = staticmethod(timed(cls.forward))
+        cls.backward = staticmethod(timed(cls.backward))
+
+    first = None
     for i in range(args.warmup + args.steps):
         if i == args.warmup:
-            if world > 1:
+            if ddp:
                 torch.distributed.barrier()
             torch.cuda.synchronize()
+            marks.clear()
             t0 = time.perf_counter()
         _, losses = step.train_step(inputs)
-        say("step %d done" % i)
         if i == 0:
             first = losses["loss"].item()
-    last = losses["loss"].item()
-    if world > 1:
+    if ddp:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    last = losses["loss"].item()
+    loss_ms = sum(a.elapsed_time(b) for a, b in marks) / args.steps
     t = torch.tensor([dt], device=dev)
-    if world > 1:
+    if ddp:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"what": "synthetic end-to-end step with stand-in networks", "n_gpus": world, "steps": args.steps,
-                          "frames_per_s": world * args.batch * args.steps / t.item(), "ms_per_step": 1e3 * t.item() / args.steps,
+        ms = 1e3 * t.item() / args.steps
+        print(json.dumps({"what": "synthetic end-to-end training step, %s networks, %d params" % (
+                              "stand-in" if args.tiny else "ResNet-18 encoder + depth decoder + pose decoder", n_params),
+                          "n_gpus": world, "ddp": ddp, "steps": args.steps, "batch_per_gpu": args.batch,
+                          "frames_per_s": world * args.batch * args.steps / t.item(), "ms_per_step": ms,
+                          "loss_ms_per_step": loss_ms, "loss_share_of_step": loss_ms / ms,
                           "first_loss": first, "last_loss": last}))
-    if world > 1:
+    if ddp:
         torch.distributed.destroy_process_group()
 
 

@@ -202,6 +202,11 @@ class ViewSynthesisLoss:
         reference's outputs[("disp", 0)] everywhere: all scales run as heads of one launch.  Same keys."""
         opt = self.opt
         srcs = self._sources()
+        if getattr(opt, "pose_model_type", "shared") == "posecnn":
+            # every head would need its own pose matrices (the translation is scaled by that head's mean inverse
+            # depth, Trainer.py:446-455) while the heads of one launch share theirs
+            raise ValueError("compute_losses_per_scale does not support pose_model_type='posecnn'; "
+                             "call compute_losses once per scale")
         disps = []
         for s in opt.scales:
             d = outputs[("disp", s)]
