@@ -69,7 +69,10 @@ constexpr int kMaxSrc = 4;
 #define VSL_TILE_H 12
 #endif
 constexpr int kTileW = 28, kIdentTileH = 12;
-constexpr int fused_tile_h(int S, bool avg) { return (S <= 2 && !avg) ? VSL_TILE_H : 12; }
+#ifndef VSL_TILE_H3
+#define VSL_TILE_H3 12
+#endif
+constexpr int fused_tile_h(int S, bool avg) { return (S <= 2 && !avg) ? VSL_TILE_H : VSL_TILE_H3; }
 constexpr int tile_threads(int th) { return 16 * (th + 4); }
 constexpr float kC1 = 0.01f * 0.01f;
 constexpr float kC2 = 0.03f * 0.03f;
@@ -839,7 +842,10 @@ struct Fused {
       // Channel by channel: the target window, its differences to the centre and its statistics are formed once and
       // serve every source frame; the per-source sums over the channels keep their order (c ascending).
       float fsum[S][2], lsum[S][2];
-      float cf[S][2][9];
+      // (!AVG) the first source's coefficients go to the LDS planes as they are formed -- they are what the planes
+      // hold unless a later source wins -- so only the later sources' sets wait in registers for the decision
+      constexpr int S0 = AVG ? 0 : 1;
+      float cf[S - S0 > 0 ? S - S0 : 1][2][9];
 #pragma unroll
       for (int s = 0; s < S; ++s) fsum[s][0] = fsum[s][1] = lsum[s][0] = lsum[s][1] = 0.0f;
 #pragma unroll
@@ -856,23 +862,30 @@ struct Fused {
           load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
           lsum[s][0] += fabsf(yw[1][1] - xw[1][1]);
           lsum[s][1] += fabsf(yw[1][2] - xw[1][2]);
+          SsimOut o[2];
           if (!NOSSIM) {
-            SsimOut o[2];
             ssim_pair_d(xw, yw[1][1], dy, sy, syy, hv.want_grad != 0, o);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              fsum[s][k] += o[k].f;
-              cf[s][k][c * 3 + 0] = o[k].A;
-              cf[s][k][c * 3 + 1] = o[k].B;
-              cf[s][k][c * 3 + 2] = o[k].G;
-            }
+            fsum[s][0] += o[0].f;
+            fsum[s][1] += o[1].f;
+          } else {
+            o[0].A = o[0].B = o[0].G = o[1].A = o[1].B = o[1].G = 0.0f;
+          }
+          if (s < S0) {
+            *reinterpret_cast<float2v*>(coef + (c * 3 + 0) * P1 + q1) = float2v{o[0].A, o[1].A};
+            *reinterpret_cast<float2v*>(coef + (c * 3 + 1) * P1 + q1) = float2v{o[0].B, o[1].B};
+            *reinterpret_cast<float2v*>(coef + (c * 3 + 2) * P1 + q1) = float2v{o[0].G, o[1].G};
           } else {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) cf[s][k][c * 3 + 0] = cf[s][k][c * 3 + 1] = cf[s][k][c * 3 + 2] = 0.0f;
+            for (int k = 0; k < 2; ++k) {
+              cf[s - S0][k][c * 3 + 0] = o[k].A;
+              cf[s - S0][k][c * 3 + 1] = o[k].B;
+              cf[s - S0][k][c * 3 + 2] = o[k].G;
+            }
           }
         }
         VSL_SCHED_FENCE();
       }
+      bool later[2] = {false, false};  // a source after the first wins the pixel
 #pragma unroll
       for (int s = 0; s < S; ++s) {
 #pragma unroll
@@ -887,14 +900,21 @@ struct Fused {
             const bool take = valid[k] && e < best[k];
             best[k] = take ? e : best[k];
             win[k] = take ? (float)s : win[k];
+            if (s >= 1) {
+              later[k] = later[k] || take;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) wc[k][j] = (s == 0 || take) ? cf[s][k][j] : wc[k][j];
+              for (int j = 0; j < 9; ++j) wc[k][j] = (s == 1 || take) ? cf[s - S0][k][j] : wc[k][j];
+            }
           }
         }
       }
-      if (!AVG) {
+      if (!AVG && S > 1) {
 #pragma unroll
-        for (int j = 0; j < 9; ++j) *reinterpret_cast<float2v*>(coef + j * P1 + q1) = float2v{wc[0][j], wc[1][j]};
+        for (int k = 0; k < 2; ++k)
+          if (later[k]) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) coef[j * P1 + q1 + k] = wc[k][j];
+          }
       }
     } else {
       // four sources: the per-source coefficient sets of the channel-outer order no longer fit the register budget

@@ -34,8 +34,14 @@ using vsl_err::fail;
 static_assert(sizeof(vsl_loss_desc) == 208 && sizeof(vsl_head) == 128, "C-ABI struct layout changed");
 constexpr int kTW = kTileW;
 constexpr int kIdTH = kIdentTileH, kIdNT = tile_threads(kIdentTileH);
-// resident workgroups per CU the fused kernel is compiled for (16 waves per CU with two sources, 12 with more)
-constexpr int fused_blocks_per_cu(int S, int nt) { return (S <= 2 ? 1024 : 768) / nt; }
+// Resident workgroups per CU the fused kernel is compiled for: as many as its LDS planes allow (160 KiB per CU), at
+// most five (the register budget of five waves per SIMD, 96, is the smallest the tile program fits without spills).
+template <int S, bool AVG>
+constexpr int fused_blocks_per_cu() {
+  constexpr int TH = fused_tile_h(S, AVG);
+  constexpr int by_lds = 160 * 1024 / (Fused<kTW, TH, tile_threads(TH), S, AVG>::LDS_FLOATS * (int)sizeof(float));
+  return by_lds > 5 ? 5 : by_lds;
+}
 
 #ifdef VSL_STAMPS
 unsigned long long* g_stamps = nullptr;
@@ -104,7 +110,7 @@ struct HeadArgs {
 };
 
 template <int S, bool AVG>
-__global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG)), fused_blocks_per_cu(S, tile_threads(fused_tile_h(S, AVG))))
+__global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG)), (fused_blocks_per_cu<S, AVG>()))
 void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
   using F = Fused<kTW, TH, NT, S, AVG>;
