@@ -19,7 +19,8 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-def oracle_run(data, fids, B, H, W, head=0, warp_scale=1.0, scales=(0,), automask=True, avg=False, no_ssim=False):
+def oracle_run(data, fids, B, H, W, head=0, warp_scale=1.0, scales=(0,), automask=True, avg=False, no_ssim=False,
+               noise_override=None):
     from oracle import vsl_oracle as O
     cfg = O.LossConfig(frame_ids=fids, scales=list(scales), height=H, width=W, automask=automask, warp_scale=warp_scale,
                        avg_reprojection=avg, no_ssim=no_ssim)
@@ -37,6 +38,8 @@ def oracle_run(data, fids, B, H, W, head=0, warp_scale=1.0, scales=(0,), automas
         else:
             outputs[("cam_T_cam", f)] = T
     noise = data["noise"][:, :1].contiguous() if avg else data["noise"]
+    if noise_override is not None:
+        noise = noise_override
     losses = O.loss_forward_backward(inputs, outputs, cfg, noise)
     # Pixels whose derivative is decided by a comparison that float32 cannot resolve (the reference evaluates the
     # warp and the errors in float64, the kernels in float32); they are compared separately:
@@ -65,13 +68,15 @@ def oracle_run(data, fids, B, H, W, head=0, warp_scale=1.0, scales=(0,), automas
     return losses, disp.grad, {f: poses[f].grad for f in fids[1:]}, sel, amb
 
 
-def gpu_run(data, fids, head=0, warp_scale=1.0, scales=(0,), noise=True, automask=True, avg=False, no_ssim=False):
+def gpu_run(data, fids, head=0, warp_scale=1.0, scales=(0,), noise=True, automask=True, avg=False, no_ssim=False,
+            noise_override=None):
     from mde_amd.ops import fused_view_synthesis_loss
     disp = data[("disp", head)].to(DEV).requires_grad_(True)
     poses = [(data["stereo_T"] if f == "s" else data[("cam_T_cam", f)]).to(DEV).requires_grad_(True) for f in fids[1:]]
     losses, ident = fused_view_synthesis_loss(
         disp, data[("image", 0)].to(DEV), [data[("image", f)].to(DEV) for f in fids[1:]], data["K"].to(DEV),
         data["inv_K"].to(DEV), poses,
+        noise_override.to(DEV) if noise_override is not None else
         (data["noise"][:, :1].contiguous() if avg else data["noise"]).to(DEV) if noise else None,
         automask=automask, avg_reprojection=avg, no_ssim=no_ssim,
         scale_weights=[1e-3 / 2 ** s for s in scales], warp_scale=warp_scale)
@@ -101,6 +106,7 @@ def test_config_matches_oracle(name):
     flags = CONFIGS[name][6] if len(CONFIGS[name]) > 6 else {}
     torch.set_num_threads(16)
     data = synth.make_batch(B, H, W, fids, seed=7)
+    automask, avg = flags.get("automask", True), flags.get("avg", False)
     ref, g_ref, gT_ref, sel_ref, amb = oracle_run(data, fids, B, H, W, warp_scale=kappa, scales=scales, **flags)
     losses, g, gT, sel = gpu_run(data, fids, warp_scale=kappa, scales=scales, **flags)
     assert abs(losses[0].item() - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
@@ -114,17 +120,33 @@ def test_config_matches_oracle(name):
     if n_amb:   # at the left-out pixels the two results differ by at most the jump of the L1 derivative
         gap = float(((g - g_ref).abs() * amb.unsqueeze(1).float()).max())
         assert gap <= 0.11 * float(g_ref.abs().max()) + 1e-12
-    # Pose gradients image by image to 1e-5.  An image that holds such a pixel may differ by one flipped
-    # decision, and because the per-pixel contributions to a pose gradient are heavy-tailed one flip can move the
-    # image's 4x4 gradient by up to a few 1e-3 (measured at 1280x384, where 3 of 8 images carried a flip); that is
-    # allowed for at most half of the images, every other image must meet 1e-5.
+    # Pose gradients image by image.  Raw: an image that holds an ambiguous pixel may differ by one flipped decision,
+    # and because the per-pixel contributions to a pose gradient are heavy-tailed one flip can move the image's 4x4
+    # gradient by a few 1e-3 -- the size of the reference's own float32 inconsistency (5e-3 between two association
+    # orders of its projection).  Every image without such a pixel must meet 1e-5, every other 5e-3.
     n_amb_img = amb.flatten(1).sum(1)
+    raw = {}
     for i, f in enumerate(fids[1:]):
         errs = [rel(gT[i][b].numpy(), gT_ref[f][b].numpy()) for b in range(B)]
-        bad = [b for b in range(B) if errs[b] > TOL]
+        raw[f] = max(errs)
         msg = "grad_T[%s] relative errors %s" % (f, ["%.1e" % e for e in errs])
-        assert len(bad) <= max(1, B // 2), msg
-        assert all(n_amb_img[b] > 0 and errs[b] <= 2e-2 for b in bad), msg
+        assert all(errs[b] <= (TOL if n_amb_img[b] == 0 else 5e-3) for b in range(B)), msg
+    # Masked: both sides evaluated once more with the ambiguous pixels (grown by the 5x5 footprint of the SSIM
+    # backward) taken out of the gradient.  The tie-break noise is an input of both: -1e9 there makes the identity
+    # term win (Trainer.py:587-599), so those pixels carry no gradient to disparity or pose on either side, and
+    # nothing that float32 cannot resolve is left.  Then every image must meet 1e-4 (the bar for a masked
+    # comparison; measured a few 1e-6).
+    if automask and n_amb and not avg:
+        grown = torch.nn.functional.max_pool2d(amb.float().unsqueeze(1), 5, 1, 2) > 0          # [B,1,H,W]
+        noise2 = torch.where(grown.expand_as(data["noise"]), torch.full_like(data["noise"], -1e9), data["noise"])
+        _, g2_ref, gT2_ref, _, amb2 = oracle_run(data, fids, B, H, W, warp_scale=kappa, scales=scales, noise_override=noise2, **flags)
+        _, g2, gT2, _ = gpu_run(data, fids, warp_scale=kappa, scales=scales, noise_override=noise2, **flags)
+        assert int((amb2 & ~grown[:, 0]).sum()) == 0
+        for i, f in enumerate(fids[1:]):
+            errs = [rel(gT2[i][b].numpy(), gT2_ref[f][b].numpy()) for b in range(B)]
+            print("grad_T[%s] %s: raw max %.1e (reference against itself: 5e-3), masked max %.1e" % (f, name, raw[f], max(errs)))
+            assert max(errs) <= 1e-4, "masked grad_T[%s] relative errors %s" % (f, ["%.1e" % e for e in errs])
+        assert rel(g2.numpy(), g2_ref.numpy()) <= TOL
     if sel_ref is not None:
         flips = int((sel.numpy() != sel_ref.numpy()).sum())
         assert flips == 0, "%d identity_selection flips" % flips
