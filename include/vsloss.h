@@ -206,6 +206,12 @@ typedef struct vsl_head {
   const float* grad_losses;   /* in [VSL_LOSS_SLOTS] or NULL = d/d losses[VSL_LOSS_TOTAL] (backward) */
   float* grad_disp;           /* out [B,1,H,W] or NULL (backward)                                  */
   float* grad_T[VSL_MAX_SOURCES]; /* out [B,4,4] each or NULL (backward)                           */
+  /* What Trainer.generate_images_pred leaves in `outputs` for validation dumps and the depth metrics
+   * (Python/Trainer.py:436,464,467; read at :129-132,627), written by the same forward launch when the
+   * pointer is not NULL: */
+  float* depth;                   /* out [B,1,H,W]   outputs[("depth",0)]                           */
+  float* sample[VSL_MAX_SOURCES]; /* out [B,H,W,2]   outputs[("sample",f)], the sampling grid        */
+  float* color[VSL_MAX_SOURCES];  /* out [B,3,H,W]   outputs[("color",f)], the warped source frame   */
 } vsl_head;
 
 int vsl_loss_forward_heads(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, void* stream);
@@ -291,6 +297,44 @@ int vsl_warp_features_fwd(const vsl_warp_desc* desc, float* out, float* sample, 
  * g_T [B,4,4]; each may be NULL.  workspace: vsl_warp_features_workspace_bytes(desc) bytes, 8-byte aligned. */
 int vsl_warp_features_bwd(const vsl_warp_desc* desc, const float* g_out, float* g_feats, float* g_disp, float* g_T,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * The same with up to VSL_MAX_WARP_TENSORS feature maps that share the sampling coordinates: what
+ * Trainer.generate_images_pred does for a source frame when the affinity term is on -- F.grid_sample of the
+ * colour frame (3 channels) and of the 25-channel affinity map with one grid (Python/Trainer.py:467-473) -- as one
+ * launch.  `out`, `g_out`, `g_feats` are HOST arrays of n device pointers; a NULL entry of g_out means that
+ * tensor has no upstream gradient, a NULL entry (or table) of g_feats that its own gradient is not wanted.
+ */
+#define VSL_MAX_WARP_TENSORS 4
+typedef struct vsl_warp_multi_desc {
+  int32_t B, H, W, n;                          /* n = number of tensors, 1..VSL_MAX_WARP_TENSORS */
+  float min_depth, max_depth, eps;
+  uint32_t reserved;
+  int32_t C[VSL_MAX_WARP_TENSORS];
+  const float* feats[VSL_MAX_WARP_TENSORS];    /* [B,C[i],H,W] */
+  const float* disp;                           /* [B,1,H,W] */
+  const float* K;                              /* [B,4,4]   */
+  const float* inv_K;                          /* [B,4,4]   */
+  const float* T;                              /* [B,4,4]   */
+} vsl_warp_multi_desc;
+
+size_t vsl_warp_multi_workspace_bytes(const vsl_warp_multi_desc* desc);
+int vsl_warp_multi_fwd(const vsl_warp_multi_desc* desc, float* const* out, float* sample, void* stream);
+int vsl_warp_multi_bwd(const vsl_warp_multi_desc* desc, const float* const* g_out, float* const* g_feats, float* g_disp,
+                       float* g_T, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Trainer.compute_affinity_reprojection_loss (Python/Trainer.py:497-516): mean over all elements of
+ * (pred - target * drop)^2 with drop = pred where rand < keep_below and 1 elsewhere (rand is the U[0,1) tensor of
+ * :502; the segmentation sums of :508-510 do not enter the value).  loss: one device float.  Backward: g_pred =
+ * g_loss[0] * d loss / d pred (the reference differentiates through `drop` as well).  workspace:
+ * vsl_affinity_loss_workspace_bytes(n) bytes, 8-byte aligned.  Deterministic (fixed-order float64 sums).
+ */
+size_t vsl_affinity_loss_workspace_bytes(long long n);
+int vsl_affinity_loss_fwd(const float* pred, const float* target, const float* rand, float keep_below, long long n,
+                          float* loss, void* workspace, size_t workspace_bytes, void* stream);
+int vsl_affinity_loss_bwd(const float* pred, const float* target, const float* rand, float keep_below, long long n,
+                          const float* g_loss, float* g_pred, void* stream);
 
 /*
  * Depth metrics of a step, Trainer.compute_depth_losses (Python/Trainer.py:622-662) with compute_depth_errors

@@ -29,6 +29,8 @@ EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", 
            "vsl_smooth_workspace_bytes", "vsl_smooth_fwd", "vsl_smooth_bwd",
            "vsl_pose_fwd", "vsl_pose_bwd", "vsl_depth_metrics_workspace_bytes", "vsl_depth_metrics",
            "vsl_warp_features_workspace_bytes", "vsl_warp_features_fwd", "vsl_warp_features_bwd",
+           "vsl_warp_multi_workspace_bytes", "vsl_warp_multi_fwd", "vsl_warp_multi_bwd",
+           "vsl_affinity_loss_workspace_bytes", "vsl_affinity_loss_fwd", "vsl_affinity_loss_bwd",
            "vsl_mean_inv_depth_workspace_bytes", "vsl_mean_inv_depth_fwd", "vsl_mean_inv_depth_bwd",
            "vsl_debug_fused_occupancy", "vsl_debug_quot", "vsl_debug_time_fused", "vsl_last_error_string", "vsl_version")
 
@@ -55,6 +57,7 @@ class Head(ctypes.Structure):
         ("losses", ctypes.c_void_p), ("identity_selection", ctypes.c_void_p),
         ("n_scales", ctypes.c_int32), ("scale_weight", ctypes.c_float * MAX_SCALES), ("flags", ctypes.c_uint32),
         ("grad_losses", ctypes.c_void_p), ("grad_disp", ctypes.c_void_p), ("grad_T", ctypes.c_void_p * MAX_SOURCES),
+        ("depth", ctypes.c_void_p), ("sample", ctypes.c_void_p * MAX_SOURCES), ("color", ctypes.c_void_p * MAX_SOURCES),
     ]
 
 
@@ -75,6 +78,19 @@ class WarpDesc(ctypes.Structure):
         ("min_depth", ctypes.c_float), ("max_depth", ctypes.c_float), ("eps", ctypes.c_float), ("reserved", ctypes.c_uint32),
         ("feats", ctypes.c_void_p), ("disp", ctypes.c_void_p), ("K", ctypes.c_void_p), ("inv_K", ctypes.c_void_p),
         ("T", ctypes.c_void_p),
+    ]
+
+
+MAX_WARP_TENSORS = 4
+
+
+class WarpMultiDesc(ctypes.Structure):
+    """Mirror of ``vsl_warp_multi_desc`` (include/vsloss.h)."""
+    _fields_ = [
+        ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("n", ctypes.c_int32),
+        ("min_depth", ctypes.c_float), ("max_depth", ctypes.c_float), ("eps", ctypes.c_float), ("reserved", ctypes.c_uint32),
+        ("C", ctypes.c_int32 * MAX_WARP_TENSORS), ("feats", ctypes.c_void_p * MAX_WARP_TENSORS),
+        ("disp", ctypes.c_void_p), ("K", ctypes.c_void_p), ("inv_K", ctypes.c_void_p), ("T", ctypes.c_void_p),
     ]
 
 
@@ -158,6 +174,18 @@ def _load():
     lib.vsl_warp_features_fwd.argtypes = [ctypes.POINTER(WarpDesc), P, P, P]
     lib.vsl_warp_features_bwd.restype = ctypes.c_int
     lib.vsl_warp_features_bwd.argtypes = [ctypes.POINTER(WarpDesc), P, P, P, P, P, SZ, P]
+    lib.vsl_warp_multi_workspace_bytes.restype = ctypes.c_size_t
+    lib.vsl_warp_multi_workspace_bytes.argtypes = [ctypes.POINTER(WarpMultiDesc)]
+    lib.vsl_warp_multi_fwd.restype = ctypes.c_int
+    lib.vsl_warp_multi_fwd.argtypes = [ctypes.POINTER(WarpMultiDesc), PT, P, P]
+    lib.vsl_warp_multi_bwd.restype = ctypes.c_int
+    lib.vsl_warp_multi_bwd.argtypes = [ctypes.POINTER(WarpMultiDesc), PT, PT, P, P, P, SZ, P]
+    lib.vsl_affinity_loss_workspace_bytes.restype = ctypes.c_size_t
+    lib.vsl_affinity_loss_workspace_bytes.argtypes = [LL]
+    lib.vsl_affinity_loss_fwd.restype = ctypes.c_int
+    lib.vsl_affinity_loss_fwd.argtypes = [P, P, P, F, LL, P, P, SZ, P]
+    lib.vsl_affinity_loss_bwd.restype = ctypes.c_int
+    lib.vsl_affinity_loss_bwd.argtypes = [P, P, P, F, LL, P, P, P]
     lib.vsl_depth_metrics_workspace_bytes.restype = ctypes.c_size_t
     lib.vsl_depth_metrics_workspace_bytes.argtypes = [ctypes.POINTER(DepthMetricsDesc)]
     lib.vsl_depth_metrics.restype = ctypes.c_int

@@ -82,6 +82,7 @@ constexpr int num_partials(int S) { return 4 + 12 * S; }
 constexpr int kPartStride = 4 + 12 * kMaxSrc;  // stride of one block's record in the workspace
 constexpr int kPrepStride = 64;                 // floats per image in KParams::prep: 12 per source, then inv_K[:3,:3]
 constexpr int kPrepInvK = 12 * kMaxSrc;
+constexpr int kOutPtrs = 1 + 2 * kMaxSrc;       // optional outputs of a head: depth, sample grid and warped frame per source
 
 struct KParams {
   int B, H, W, S;
@@ -112,6 +113,8 @@ struct KParams {
   float* prep;       // [B][kPrepStride] per-image projection matrices and inv_K, written by prepare_matrices() in a
                      // launch before the tile programs, or null: every workgroup then forms them itself
   int want_grad;
+  float** out_table;  // [heads][kOutPtrs] output pointers (each may be null), written by the launch before the tile
+                      // programs; null: no head wants outputs
 #ifdef VSL_STAMPS
   unsigned long long* stamps;  // diagnostic build: [blocks][waves][16] shader-clock samples
 #endif
@@ -128,9 +131,10 @@ struct HeadView {
   unsigned int* counter;
   float cst_ssim, cst_l1;
   int want_grad;  // 0: forward only (no coefficients, no gradient planes)
+  int head;       // index into KParams::out_table
 };
 VSL_DEV HeadView head_view(const KParams& kp) {
-  return HeadView{kp.disp, kp.gphoto, kp.gedge, kp.ident_sel, kp.partials, kp.counter, kp.cst_ssim, kp.cst_l1, kp.want_grad};
+  return HeadView{kp.disp, kp.gphoto, kp.gedge, kp.ident_sel, kp.partials, kp.counter, kp.cst_ssim, kp.cst_l1, kp.want_grad, 0};
 }
 
 // ----------------------------------------------------------------------------
@@ -655,7 +659,9 @@ struct Ident {
 // ----------------------------------------------------------------------------
 // HALO = 2: the full program (loss and everything for the backward).  HALO = 1: forward only -- phases 0 and 1
 // on the tile grown by 1, then phase_forward instead of phases 2 and 3 (no coefficients, no gradients).
-template <int TW, int TH, int NT, int S, bool AVG, int HALO = 2>
+// OUT: the instantiation that also writes the optional outputs of phase 1 (vsl_head.depth / sample / color); the
+// plain one carries no trace of them (their tests alone cost the two-source kernel 22 spilled scalar registers and 11 %).
+template <int TW, int TH, int NT, int S, bool AVG, int HALO = 2, bool OUT = false>
 struct Fused {
   static_assert(TW % 2 == 0, "tile width must be even");
   static_assert(HALO == 1 || HALO == 2, "halo is 1 (forward only) or 2");
@@ -711,6 +717,27 @@ struct Fused {
 #endif
   }
 
+  // ---- optional outputs of phase 1 (vsl_head.depth / sample / color): OUT instantiations only ----
+  // R2 position (ry, rx) is a pixel of the tile, not a halo position or one past the image's edge
+  static VSL_DEV bool is_tile_pixel(const KParams& kp, const Block& bk, int ry, int rx) {
+    return ry >= HALO && ry < HALO + TH && rx >= HALO && rx < HALO + TW && bk.y0 - HALO + ry < kp.H && bk.x0 - HALO + rx < kp.W;
+  }
+  static VSL_DEV void emit_depth(const KParams& kp, const HeadView& hv, const Block& bk, int ry, int rx, unsigned pix, float D) {
+    float* out = kp.out_table[hv.head * kOutPtrs];
+    if (out && is_tile_pixel(kp, bk, ry, rx)) store_f32_at(out + (size_t)bk.b * kp.H * kp.W, pix << 2, D);
+  }
+  static VSL_DEV void emit_sample(const KParams& kp, const HeadView& hv, const Block& bk, int ry, int rx, unsigned pix, int s,
+                                  float gx, float gy) {
+    float* out = kp.out_table[hv.head * kOutPtrs + 1 + s];
+    if (out && is_tile_pixel(kp, bk, ry, rx))
+      *reinterpret_cast<float2v*>(out + 2 * ((size_t)bk.b * kp.H * kp.W + pix)) = float2v{gx, gy};
+  }
+  static VSL_DEV void emit_color(const KParams& kp, const HeadView& hv, const Block& bk, int ry, int rx, unsigned pix, int s,
+                                 int c, float v) {
+    float* out = kp.out_table[hv.head * kOutPtrs + 1 + kMaxSrc + s];
+    if (out && is_tile_pixel(kp, bk, ry, rx)) store_f32_at(out + ((size_t)bk.b * 3 + c) * kp.H * kp.W, pix << 2, v);
+  }
+
   // ---- phase 1: two horizontally adjacent R2 positions per thread -------------------
   // Every thread warps exactly one pair of R2 and keeps where its taps were; the threads whose
   // pair is interior use that again in phase 3.
@@ -745,6 +772,7 @@ struct Fused {
       // disp_to_depth and the back-projected ray, layers.py:21-25,163-169
       const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
       const float D = quot(1.0f, divisor(sd));
+      if constexpr (OUT) emit_depth(kp, hv, bk, ry, rx0 + k, pix, D);
       const float fx = (float)px;
       float X[3];
 #pragma unroll
@@ -772,6 +800,7 @@ struct Fused {
         const float u = quot(cam[0], by_den), v = quot(cam[1], by_den);
         const float gx = VSL_FMUL(VSL_FSUB(quot(u, by_wm1), 0.5f), 2.0f);
         const float gy = VSL_FMUL(VSL_FSUB(quot(v, by_hm1), 0.5f), 2.0f);
+        if constexpr (OUT) emit_sample(kp, hv, bk, ry, rx0 + k, pix, s, gx, gy);
         const TileTaps tx = tile_taps(gx, W), ty = tile_taps(gy, H);
         const float* sp = src_image(kp, s) + (size_t)bk.b * 3 * HW;
         // both x taps of a row come from one 8-byte load at min(x0, W-2)
@@ -787,7 +816,9 @@ struct Fused {
         for (int c = 0; c < 3; ++c) {
           const float* pc = sp + (size_t)c * HW;
           const TexelPair a = load_texel_pair_at(pc, o0 << 2), b = load_texel_pair_at(pc, o1 << 2);
-          lds[OFF_WRP + (s * 3 + c) * P2 + p2] = a.lo * w00 + a.hi * w01 + b.lo * w10 + b.hi * w11;
+          const float wv = a.lo * w00 + a.hi * w01 + b.lo * w10 + b.hi * w11;
+          lds[OFF_WRP + (s * 3 + c) * P2 + p2] = wv;
+          if constexpr (OUT) emit_color(kp, hv, bk, ry, rx0 + k, pix, s, c, wv);
         }
         Chain& ch = st.ch[k][s];
         ch.tx = txe;

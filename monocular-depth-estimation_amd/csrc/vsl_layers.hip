@@ -427,15 +427,38 @@ int check_hw(int B, int H, int W) {
 // the same rounding recipe as the kernels above, so they equal the module-by-module result bit for bit.
 // Grid: (pixel blocks, channel groups, images); a thread handles one pixel and `cg` consecutive channels.
 // ---------------------------------------------------------------------------
+// Up to VSL_MAX_WARP_TENSORS feature maps share the sampling coordinates of one launch (the colour frame and the
+// 25-channel affinity map of a source, Python/Trainer.py:467-473): their channel groups are numbered one tensor
+// after the other, gstart[t] is the first group of tensor t.
+constexpr int kWarpMaxT = VSL_MAX_WARP_TENSORS;
 struct WarpArgs {
-  const float* feats;
+  const float* feats[kWarpMaxT];
+  int C[kWarpMaxT];
+  int gstart[kWarpMaxT + 1];
   const float* disp;
   const float* K;
   const float* inv_K;
   const float* T;
-  int C, H, W, cg;
+  int H, W, cg;
   float a_disp, c_disp, eps;
 };
+struct WarpPtrs {  // one pointer per tensor: outputs, upstream gradients or gradient accumulators (entries may be null)
+  float* p[kWarpMaxT];
+};
+// which tensor channel group g belongs to, and that tensor's fields, through compile-time indices only (a run-time
+// index into a by-value argument struct would move it to scratch memory)
+struct WarpSel {
+  const float* feats;
+  float* ptr;
+  int C, local_group;
+};
+__device__ __forceinline__ WarpSel warp_select(const WarpArgs& a, const WarpPtrs& q, int g) {
+  WarpSel r{a.feats[0], q.p[0], a.C[0], g};
+#pragma unroll
+  for (int t = 1; t < kWarpMaxT; ++t)
+    if (g >= a.gstart[t]) r = WarpSel{a.feats[t], q.p[t], a.C[t], g - a.gstart[t]};
+  return r;
+}
 
 struct WarpPixel {
   float X[3];    // back-projected point
@@ -467,8 +490,9 @@ __device__ __forceinline__ WarpPixel warp_pixel(const WarpArgs& a, const float P
   return o;
 }
 
-__global__ __launch_bounds__(256) void k_warp_fwd(WarpArgs a, float* __restrict__ out, float* __restrict__ sample) {
+__global__ __launch_bounds__(256) void k_warp_fwd(WarpArgs a, WarpPtrs outs, float* __restrict__ sample) {
   const int b = blockIdx.z, g = blockIdx.y;
+  const WarpSel sel = warp_select(a, outs, g);
   const int HW = a.H * a.W;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= HW) return;
@@ -485,18 +509,21 @@ __global__ __launch_bounds__(256) void k_warp_fwd(WarpArgs a, float* __restrict_
   const int o00 = ty.i0 * a.W + tx.i0, o01 = ty.i0 * a.W + tx.i1, o10 = ty.i1 * a.W + tx.i0, o11 = ty.i1 * a.W + tx.i1;
   const float w00 = (1.0f - tx.t) * (1.0f - ty.t), w01 = tx.t * (1.0f - ty.t);
   const float w10 = (1.0f - tx.t) * ty.t, w11 = tx.t * ty.t;
-  const int c1 = min(a.C, (g + 1) * a.cg);
-  for (int c = g * a.cg; c < c1; ++c) {
-    const float* pl = a.feats + ((size_t)b * a.C + c) * HW;
-    out[((size_t)b * a.C + c) * HW + p] = pl[o00] * w00 + pl[o01] * w01 + pl[o10] * w10 + pl[o11] * w11;
+  const int c1 = min(sel.C, (sel.local_group + 1) * a.cg);
+  for (int c = sel.local_group * a.cg; c < c1; ++c) {
+    const float* pl = sel.feats + ((size_t)b * sel.C + c) * HW;
+    sel.ptr[((size_t)b * sel.C + c) * HW + p] = pl[o00] * w00 + pl[o01] * w01 + pl[o10] * w10 + pl[o11] * w11;
   }
 }
 
 // Backward, first pass: the channel group's share of d L / d (ix, iy) of its pixel into partial[b][g][p] and the
 // scatter of d L / d feats (float atomics; g_feats zeroed by the host).
-__global__ __launch_bounds__(256) void k_warp_bwd_taps(WarpArgs a, const float* __restrict__ g_out, float* __restrict__ g_feats,
+__global__ __launch_bounds__(256) void k_warp_bwd_taps(WarpArgs a, WarpPtrs g_outs, WarpPtrs g_featss,
                                                        float* __restrict__ partial) {
   const int b = blockIdx.z, g = blockIdx.y;
+  const WarpSel sel = warp_select(a, g_outs, g);
+  const float* g_out = sel.ptr;  // null: this tensor has no upstream gradient
+  float* g_feats = warp_select(a, g_featss, g).ptr;
   const int HW = a.H * a.W;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= HW) return;
@@ -508,15 +535,15 @@ __global__ __launch_bounds__(256) void k_warp_bwd_taps(WarpArgs a, const float* 
   const float w00 = (1.0f - tx.t) * (1.0f - ty.t), w01 = tx.t * (1.0f - ty.t);
   const float w10 = (1.0f - tx.t) * ty.t, w11 = tx.t * ty.t;
   float gix = 0.0f, giy = 0.0f;
-  const int c1 = min(a.C, (g + 1) * a.cg);
-  for (int c = g * a.cg; c < c1; ++c) {
-    const float go = g_out[((size_t)b * a.C + c) * HW + p];
-    const float* pl = a.feats + ((size_t)b * a.C + c) * HW;
+  const int c1 = g_out ? min(sel.C, (sel.local_group + 1) * a.cg) : 0;
+  for (int c = sel.local_group * a.cg; c < c1; ++c) {
+    const float go = g_out[((size_t)b * sel.C + c) * HW + p];
+    const float* pl = sel.feats + ((size_t)b * sel.C + c) * HW;
     const float v00 = pl[o00], v01 = pl[o01], v10 = pl[o10], v11 = pl[o11];
     gix = fmaf(go, (1.0f - ty.t) * (v01 - v00) + ty.t * (v11 - v10), gix);
     giy = fmaf(go, (1.0f - tx.t) * (v10 - v00) + tx.t * (v11 - v01), giy);
     if (g_feats) {
-      float* gp = g_feats + ((size_t)b * a.C + c) * HW;
+      float* gp = g_feats + ((size_t)b * sel.C + c) * HW;
       atomicAdd(gp + o00, go * w00);
       atomicAdd(gp + o01, go * w01);
       atomicAdd(gp + o10, go * w10);
@@ -585,6 +612,7 @@ constexpr int kWarpGroupChannels = 8;
 static_assert(sizeof(vsl_warp_desc) == 72, "vsl_warp_desc layout is part of the ABI");
 
 int warp_groups(int C) { return (C + kWarpGroupChannels - 1) / kWarpGroupChannels; }
+static_assert(sizeof(vsl_warp_multi_desc) == 112, "vsl_warp_multi_desc layout is part of the ABI");
 
 int check_warp(const vsl_warp_desc* d) {
   if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "warp descriptor is null");
@@ -597,14 +625,57 @@ int check_warp(const vsl_warp_desc* d) {
   return VSL_OK;
 }
 
-WarpArgs warp_args(const vsl_warp_desc* d) {
-  WarpArgs a;
-  a.feats = d->feats;
+// the single-tensor descriptor as a one-entry multi-tensor descriptor
+vsl_warp_multi_desc as_multi(const vsl_warp_desc* d) {
+  vsl_warp_multi_desc m{};
+  m.B = d->B;
+  m.H = d->H;
+  m.W = d->W;
+  m.n = 1;
+  m.min_depth = d->min_depth;
+  m.max_depth = d->max_depth;
+  m.eps = d->eps;
+  m.C[0] = d->C;
+  m.feats[0] = d->feats;
+  m.disp = d->disp;
+  m.K = d->K;
+  m.inv_K = d->inv_K;
+  m.T = d->T;
+  return m;
+}
+
+int check_warp_multi(const vsl_warp_multi_desc* d) {
+  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "warp descriptor is null");
+  if (int rc = check_hw(d->B, d->H, d->W)) return rc;
+  if (d->H < 2 || d->W < 2) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: need H >= 2 and W >= 2");
+  if (d->n < 1 || d->n > VSL_MAX_WARP_TENSORS) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: need 1..VSL_MAX_WARP_TENSORS tensors");
+  long long groups = 0;
+  for (int t = 0; t < d->n; ++t) {
+    if (d->C[t] < 1) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: C out of range");
+    if ((long long)d->B * d->C[t] * d->H * d->W >= (1LL << 31)) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: B*C*H*W must be < 2^31");
+    if (!d->feats[t]) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: NULL tensor");
+    groups += warp_groups(d->C[t]);
+  }
+  if (groups > 65535) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: C out of range");
+  if (!(d->min_depth > 0.0f) || !(d->max_depth > d->min_depth)) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: depth range");
+  if (!d->disp || !d->K || !d->inv_K || !d->T) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: NULL tensor");
+  return VSL_OK;
+}
+
+WarpArgs warp_args(const vsl_warp_multi_desc* d) {
+  WarpArgs a{};
+  int g = 0;
+  for (int t = 0; t < kWarpMaxT; ++t) {
+    a.feats[t] = t < d->n ? d->feats[t] : nullptr;
+    a.C[t] = t < d->n ? d->C[t] : 0;
+    a.gstart[t] = t < d->n ? g : 0x7fffffff;   // tensors that do not exist start beyond every group
+    if (t < d->n) g += warp_groups(d->C[t]);
+  }
+  a.gstart[kWarpMaxT] = g;                      // total number of groups
   a.disp = d->disp;
   a.K = d->K;
   a.inv_K = d->inv_K;
   a.T = d->T;
-  a.C = d->C;
   a.H = d->H;
   a.W = d->W;
   a.cg = kWarpGroupChannels;
@@ -614,40 +685,52 @@ WarpArgs warp_args(const vsl_warp_desc* d) {
   return a;
 }
 
-}  // namespace
-
-extern "C" {
-
-size_t vsl_warp_features_workspace_bytes(const vsl_warp_desc* d) {
-  if (!d || d->B < 1 || d->C < 1 || d->H < 1 || d->W < 1) return 0;
+size_t warp_multi_workspace(const vsl_warp_multi_desc* d) {
   const size_t HW = (size_t)d->H * d->W;
   const size_t blocks = (HW + 255) / 256;
-  return ((size_t)d->B * warp_groups(d->C) * HW * 2 + (size_t)d->B * blocks * 12) * sizeof(float);
+  size_t groups = 0;
+  for (int t = 0; t < d->n && t < VSL_MAX_WARP_TENSORS; ++t) groups += warp_groups(d->C[t]);
+  return ((size_t)d->B * groups * HW * 2 + (size_t)d->B * blocks * 12) * sizeof(float);
 }
 
-int vsl_warp_features_fwd(const vsl_warp_desc* d, float* out, float* sample, void* stream) {
-  if (int rc = check_warp(d)) return rc;
+int warp_multi_fwd(const vsl_warp_multi_desc* d, float* const* out, float* sample, void* stream) {
+  if (int rc = check_warp_multi(d)) return rc;
   if (!out) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: NULL output");
+  WarpPtrs o{};
+  for (int t = 0; t < d->n; ++t) {
+    if (!out[t]) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features: NULL output");
+    o.p[t] = out[t];
+  }
+  const WarpArgs a = warp_args(d);
   const int bx = (d->H * d->W + 255) / 256;
-  hipLaunchKernelGGL(k_warp_fwd, dim3(bx, warp_groups(d->C), d->B), dim3(256), 0, (hipStream_t)stream, warp_args(d), out, sample);
+  hipLaunchKernelGGL(k_warp_fwd, dim3(bx, a.gstart[kWarpMaxT], d->B), dim3(256), 0, (hipStream_t)stream, a, o, sample);
   return launch_status();
 }
 
-int vsl_warp_features_bwd(const vsl_warp_desc* d, const float* g_out, float* g_feats, float* g_disp, float* g_T,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-  if (int rc = check_warp(d)) return rc;
+int warp_multi_bwd(const vsl_warp_multi_desc* d, const float* const* g_out, float* const* g_feats, float* g_disp, float* g_T,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_warp_multi(d)) return rc;
   if (!g_out || !workspace) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features backward: NULL tensor");
-  if (workspace_bytes < vsl_warp_features_workspace_bytes(d))
+  if (workspace_bytes < warp_multi_workspace(d))
     return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "warp_features backward: workspace too small");
   if ((uintptr_t)workspace % 8) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features backward: workspace must be 8-byte aligned");
   const size_t HW = (size_t)d->H * d->W;
-  const int bx = (int)((HW + 255) / 256), groups = warp_groups(d->C);
-  if (g_feats && hipMemsetAsync(g_feats, 0, (size_t)d->B * d->C * HW * sizeof(float), (hipStream_t)stream) != hipSuccess)
-    return fail(VSL_ERR_LAUNCH_FAILED, "warp_features backward: memset failed");
+  WarpPtrs go{}, gf{};
+  bool any = false;
+  for (int t = 0; t < d->n; ++t) {
+    go.p[t] = const_cast<float*>(g_out[t]);
+    gf.p[t] = (g_feats && g_out[t]) ? g_feats[t] : nullptr;
+    any = any || g_out[t] != nullptr;
+    if (g_feats && g_feats[t] &&
+        hipMemsetAsync(g_feats[t], 0, (size_t)d->B * d->C[t] * HW * sizeof(float), (hipStream_t)stream) != hipSuccess)
+      return fail(VSL_ERR_LAUNCH_FAILED, "warp_features backward: memset failed");
+  }
+  if (!any) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features backward: NULL tensor");
+  const WarpArgs a = warp_args(d);
+  const int bx = (int)((HW + 255) / 256), groups = a.gstart[kWarpMaxT];
   float* partial = (float*)workspace;
   float* sums = partial + (size_t)d->B * groups * HW * 2;
-  const WarpArgs a = warp_args(d);
-  hipLaunchKernelGGL(k_warp_bwd_taps, dim3(bx, groups, d->B), dim3(256), 0, (hipStream_t)stream, a, g_out, g_feats, partial);
+  hipLaunchKernelGGL(k_warp_bwd_taps, dim3(bx, groups, d->B), dim3(256), 0, (hipStream_t)stream, a, go, gf, partial);
   if (g_disp || g_T) {
     hipLaunchKernelGGL(k_warp_bwd_chain, dim3(bx, d->B), dim3(256), 0, (hipStream_t)stream, a, (const float*)partial, groups,
                        g_disp, sums);
@@ -656,6 +739,106 @@ int vsl_warp_features_bwd(const vsl_warp_desc* d, const float* g_out, float* g_f
                          g_T, (float*)nullptr);
   }
   return launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// Affinity reprojection loss (Python/Trainer.py:497-516): mean((pred - target * drop)^2), drop = pred where
+// rand < keep_below, else 1.  Forward: float64 partial sum per workgroup in fixed order, finished by one workgroup.
+// ---------------------------------------------------------------------------
+constexpr int kAffBlocks = 512;
+
+__device__ __forceinline__ float affinity_residual(float p, float t, float r, float keep_below, float& slope) {
+  const bool keep = r < keep_below;
+  slope = keep ? 1.0f - t : 1.0f;        // d (pred - target * drop) / d pred, through drop = pred as autograd does
+  return keep ? p - t * p : p - t;
+}
+
+__global__ __launch_bounds__(256) void k_affinity_partial(const float* __restrict__ pred, const float* __restrict__ target,
+                                                          const float* __restrict__ rnd, float keep_below, long long n,
+                                                          double* __restrict__ partial) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float slope;
+    const float e = affinity_residual(pred[i], target[i], rnd[i], keep_below, slope);
+    acc += (double)(e * e);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void k_affinity_finish(const double* __restrict__ partial, int nblocks, double inv_n,
+                                                         float* __restrict__ loss) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(red[0] * inv_n);
+}
+
+__global__ __launch_bounds__(256) void k_affinity_bwd(const float* __restrict__ pred, const float* __restrict__ target,
+                                                      const float* __restrict__ rnd, float keep_below, long long n,
+                                                      const float* __restrict__ g_loss, float two_over_n,
+                                                      float* __restrict__ g_pred) {
+  const float g = g_loss[0] * two_over_n;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float slope;
+    const float e = affinity_residual(pred[i], target[i], rnd[i], keep_below, slope);
+    g_pred[i] = g * e * slope;
+  }
+}
+
+int affinity_blocks(long long n) {
+  const long long b = (n + 255) / 256;
+  return (int)(b < kAffBlocks ? b : kAffBlocks);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vsl_warp_features_workspace_bytes(const vsl_warp_desc* d) {
+  if (!d || d->B < 1 || d->C < 1 || d->H < 1 || d->W < 1) return 0;
+  const vsl_warp_multi_desc m = as_multi(d);
+  return warp_multi_workspace(&m);
+}
+
+int vsl_warp_features_fwd(const vsl_warp_desc* d, float* out, float* sample, void* stream) {
+  if (int rc = check_warp(d)) return rc;
+  const vsl_warp_multi_desc m = as_multi(d);
+  return warp_multi_fwd(&m, &out, sample, stream);
+}
+
+int vsl_warp_features_bwd(const vsl_warp_desc* d, const float* g_out, float* g_feats, float* g_disp, float* g_T,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_warp(d)) return rc;
+  if (!g_out || !workspace) return fail(VSL_ERR_INVALID_ARGUMENT, "warp_features backward: NULL tensor");
+  const vsl_warp_multi_desc m = as_multi(d);
+  return warp_multi_bwd(&m, &g_out, &g_feats, g_disp, g_T, workspace, workspace_bytes, stream);
+}
+
+size_t vsl_warp_multi_workspace_bytes(const vsl_warp_multi_desc* d) {
+  if (!d || d->B < 1 || d->H < 1 || d->W < 1 || d->n < 1 || d->n > VSL_MAX_WARP_TENSORS) return 0;
+  return warp_multi_workspace(d);
+}
+
+int vsl_warp_multi_fwd(const vsl_warp_multi_desc* d, float* const* out, float* sample, void* stream) {
+  return warp_multi_fwd(d, out, sample, stream);
+}
+
+int vsl_warp_multi_bwd(const vsl_warp_multi_desc* d, const float* const* g_out, float* const* g_feats, float* g_disp, float* g_T,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  return warp_multi_bwd(d, g_out, g_feats, g_disp, g_T, workspace, workspace_bytes, stream);
 }
 
 int vsl_disp_to_depth_fwd(const float* disp, float* scaled, float* depth, long long n, float min_depth, float max_depth,
@@ -795,6 +978,27 @@ int vsl_smooth_bwd(const float* disp, const float* img, const float* g_loss, flo
   const float inv_nx = (float)(1.0 / ((double)B * H * (W - 1))), inv_ny = (float)(1.0 / ((double)B * (H - 1) * W));
   hipLaunchKernelGGL((k_smooth<true>), dim3(bx, B), dim3(256), 0, (hipStream_t)stream, disp, img, g_loss, g_disp, C, H, W,
                      inv_nx, inv_ny);
+  return launch_status();
+}
+
+size_t vsl_affinity_loss_workspace_bytes(long long n) { return n < 1 ? 0 : (size_t)affinity_blocks(n) * sizeof(double); }
+
+int vsl_affinity_loss_fwd(const float* pred, const float* target, const float* rnd, float keep_below, long long n, float* loss,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pred || !target || !rnd || !loss || !workspace || n < 1) return fail(VSL_ERR_INVALID_ARGUMENT, "affinity loss: bad arguments");
+  if (workspace_bytes < vsl_affinity_loss_workspace_bytes(n)) return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "affinity loss: workspace too small");
+  if ((uintptr_t)workspace % 8) return fail(VSL_ERR_INVALID_ARGUMENT, "affinity loss: workspace must be 8-byte aligned");
+  const int nb = affinity_blocks(n);
+  hipLaunchKernelGGL(k_affinity_partial, dim3(nb), dim3(256), 0, (hipStream_t)stream, pred, target, rnd, keep_below, n, (double*)workspace);
+  hipLaunchKernelGGL(k_affinity_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nb, 1.0 / (double)n, loss);
+  return launch_status();
+}
+
+int vsl_affinity_loss_bwd(const float* pred, const float* target, const float* rnd, float keep_below, long long n,
+                          const float* g_loss, float* g_pred, void* stream) {
+  if (!pred || !target || !rnd || !g_loss || !g_pred || n < 1) return fail(VSL_ERR_INVALID_ARGUMENT, "affinity loss backward: bad arguments");
+  hipLaunchKernelGGL(k_affinity_bwd, dim3(affinity_blocks(n) * 4), dim3(256), 0, (hipStream_t)stream, pred, target, rnd, keep_below, n,
+                     g_loss, (float)(2.0 / (double)n), g_pred);
   return launch_status();
 }
 

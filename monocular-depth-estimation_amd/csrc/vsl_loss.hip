@@ -31,7 +31,7 @@ namespace {
 using namespace vsl;
 using vsl_err::fail;
 
-static_assert(sizeof(vsl_loss_desc) == 208 && sizeof(vsl_head) == 128, "C-ABI struct layout changed");
+static_assert(sizeof(vsl_loss_desc) == 208 && sizeof(vsl_head) == 200, "C-ABI struct layout changed");
 constexpr int kTW = kTileW;
 constexpr int kIdTH = kIdentTileH, kIdNT = tile_threads(kIdentTileH);
 // Resident workgroups per CU the fused kernel is compiled for: as many as its LDS planes allow (160 KiB per CU), at
@@ -109,11 +109,11 @@ struct HeadArgs {
   int want_grad[VSL_MAX_HEADS];
 };
 
-template <int S, bool AVG>
+template <int S, bool AVG, bool OUT>
 __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG)), (fused_blocks_per_cu<S, AVG>()))
 void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
-  using F = Fused<kTW, TH, NT, S, AVG>;
+  using F = Fused<kTW, TH, NT, S, AVG, 2, OUT>;
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x;
   typename F::Block bk;
@@ -124,7 +124,7 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   // the head's pointers and constants (a patched copy of the argument struct would end up in scratch memory)
   const HeadView hv{ha.disp[head],     ha.gphoto[head],  ha.gedge[head],    ha.ident_sel[head],
                     ha.partials[head], ha.counter[head], ha.cst_ssim[head], ha.cst_l1[head],
-                    ha.want_grad[head]};
+                    ha.want_grad[head], head};
 
   ThreadState<S> st;
 #ifdef VSL_STAMPS
@@ -168,10 +168,10 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
 // --------------------------------------------------------------------------
 // forward-only tile kernel (every head of the launch without gradients: validation, teacher heads)
 // --------------------------------------------------------------------------
-template <int S, bool AVG>
+template <int S, bool AVG, bool OUT>
 __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG))) void vsl_forward_kernel(const KParams kp_in, const HeadArgs ha) {
   constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
-  using F = Fused<kTW, TH, NT, S, AVG, 1>;
+  using F = Fused<kTW, TH, NT, S, AVG, 1, OUT>;
   __shared__ __align__(16) float lds[F::LDS_FLOATS];
   const int tid = threadIdx.x;
   typename F::Block bk;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG))) void vsl_forwar
   const KParams& kp = kp_in;
   const HeadView hv{ha.disp[head],     ha.gphoto[head],  ha.gedge[head],    ha.ident_sel[head],
                     ha.partials[head], ha.counter[head], ha.cst_ssim[head], ha.cst_l1[head],
-                    0};
+                    0, head};
   ThreadState<S> st;
   F::phase0(kp, hv, bk, tid, st);
   F::phase1(kp, hv, bk, tid, lds, st);
@@ -198,13 +198,25 @@ __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG))) void vsl_forwar
 // --------------------------------------------------------------------------
 // identity minimum
 // --------------------------------------------------------------------------
+// optional output pointers of every head (vsl_head.depth / sample / color), handed to the tile programs through a table
+// in the workspace: the launch in front of them stores it
+struct OutArgs {
+  int n_heads;
+  float* ptr[VSL_MAX_HEADS][kOutPtrs];
+};
+__device__ __forceinline__ void store_out_table(const KParams& kp, const OutArgs& oa, int tid, int nt) {
+  if (!kp.out_table) return;
+  for (int i = tid; i < oa.n_heads * kOutPtrs; i += nt) kp.out_table[i] = oa.ptr[i / kOutPtrs][i % kOutPtrs];
+}
+
 template <int S, bool AVG>
-__global__ __launch_bounds__(kIdNT) void vsl_ident_kernel(const KParams kp) {
+__global__ __launch_bounds__(kIdNT) void vsl_ident_kernel(const KParams kp, const OutArgs oa) {
   using I = Ident<kTW, kIdTH, kIdNT, S, AVG>;
   __shared__ __align__(16) float lds[I::LDS_FLOATS];
   typename I::Block bk;
   int head = 0;
   // this launch precedes the tile programs of the step: its first workgroup also writes the per-image matrices
+  if (blockIdx.x == 0) store_out_table(kp, oa, threadIdx.x, kIdNT);
   if (kp.prep && blockIdx.x == 0)
     for (int i = threadIdx.x; i < kp.B * kPrepStride; i += kIdNT) kp.prep[i] = prep_entry(kp, i / kPrepStride, i % kPrepStride);
   if (swizzled_tile<kIdTH>(kp, 1, head, bk.b, bk.x0, bk.y0) < 0) return;
@@ -214,7 +226,8 @@ __global__ __launch_bounds__(kIdNT) void vsl_ident_kernel(const KParams kp) {
 }
 
 // the per-image matrices alone, for steps that launch no identity pass (no auto-masking, or a shared identity minimum)
-__global__ void vsl_prep_kernel(const KParams kp) {
+__global__ void vsl_prep_kernel(const KParams kp, const OutArgs oa) {
+  if (blockIdx.x == 0) store_out_table(kp, oa, threadIdx.x, blockDim.x);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kp.B * kPrepStride; i += gridDim.x * blockDim.x)
     kp.prep[i] = prep_entry(kp, i / kPrepStride, i % kPrepStride);
 }
@@ -432,7 +445,7 @@ inline unsigned swizzled_grid(int tiles) { return 8u * (unsigned)((tiles + 7) / 
 
 struct Layout {
   int tiles_x, tiles_y, tiles_per_image, blocks;
-  size_t off_partials, off_gphoto, off_gedge, off_idmin, off_img, off_gT, off_c12, off_counter, off_prep, total;
+  size_t off_partials, off_gphoto, off_gedge, off_idmin, off_img, off_gT, off_c12, off_counter, off_prep, off_outs, total;
 };
 
 inline int desc_tile_h(const vsl_loss_desc* d) {
@@ -464,6 +477,8 @@ Layout make_layout(int B, int H, int W, int th) {
   o += align256((size_t)B * 2 * sizeof(float));
   L.off_prep = o;
   o += align256((size_t)B * kPrepStride * sizeof(float));
+  L.off_outs = o;
+  o += align256((size_t)VSL_MAX_HEADS * kOutPtrs * sizeof(float*));
   L.total = o;
   return L;
 }
@@ -485,7 +500,7 @@ int check_desc(const vsl_loss_desc* d) {
   return VSL_OK;
 }
 
-template <int S, bool AVG>
+template <int S, bool AVG, bool OUT>
 int launch_fused(const KParams& kp, const HeadArgs& ha, dim3 grid, hipStream_t stream) {
   constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
   using F = Fused<kTW, TH, NT, S, AVG>;
@@ -496,7 +511,7 @@ int launch_fused(const KParams& kp, const HeadArgs& ha, dim3 grid, hipStream_t s
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return fail(VSL_ERR_LAUNCH_FAILED, "hipGetDevice failed");
   if (dev >= 64 || !((configured >> dev) & 1ull)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vsl_fused_kernel<S, AVG>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vsl_fused_kernel<S, AVG, OUT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(VSL_ERR_LAUNCH_FAILED, "hipFuncSetAttribute(max dynamic LDS) failed");
     if (dev < 64) configured |= 1ull << dev;
@@ -505,38 +520,45 @@ int launch_fused(const KParams& kp, const HeadArgs& ha, dim3 grid, hipStream_t s
 #ifdef VSL_STAMPS
   if (const char* e = getenv("VSL_DEBUG_EXTRA_LDS")) launch_lds += (size_t)atoi(e);  // diagnostic: fewer resident blocks
 #endif
-  hipLaunchKernelGGL((vsl_fused_kernel<S, AVG>), grid, dim3(NT), launch_lds, stream, kp, ha);
+  hipLaunchKernelGGL((vsl_fused_kernel<S, AVG, OUT>), grid, dim3(NT), launch_lds, stream, kp, ha);
   return VSL_OK;
 }
 
 template <int S>
 void launch_forward_s(const KParams& kp, const HeadArgs& ha, bool avg, dim3 grid, hipStream_t stream) {
   constexpr int NTF = tile_threads(fused_tile_h(S, false)), NTA = tile_threads(fused_tile_h(S, true));
-  if (avg)
-    hipLaunchKernelGGL((vsl_forward_kernel<S, true>), grid, dim3(NTA), 0, stream, kp, ha);
+  const bool out = kp.out_table != nullptr;
+  if (avg && out)
+    hipLaunchKernelGGL((vsl_forward_kernel<S, true, true>), grid, dim3(NTA), 0, stream, kp, ha);
+  else if (avg)
+    hipLaunchKernelGGL((vsl_forward_kernel<S, true, false>), grid, dim3(NTA), 0, stream, kp, ha);
+  else if (out)
+    hipLaunchKernelGGL((vsl_forward_kernel<S, false, true>), grid, dim3(NTF), 0, stream, kp, ha);
   else
-    hipLaunchKernelGGL((vsl_forward_kernel<S, false>), grid, dim3(NTF), 0, stream, kp, ha);
+    hipLaunchKernelGGL((vsl_forward_kernel<S, false, false>), grid, dim3(NTF), 0, stream, kp, ha);
 }
 
 template <int S>
 int launch_fused_s(const KParams& kp, const HeadArgs& ha, bool avg, dim3 grid, hipStream_t stream) {
-  return avg ? launch_fused<S, true>(kp, ha, grid, stream) : launch_fused<S, false>(kp, ha, grid, stream);
+  const bool out = kp.out_table != nullptr;
+  if (avg) return out ? launch_fused<S, true, true>(kp, ha, grid, stream) : launch_fused<S, true, false>(kp, ha, grid, stream);
+  return out ? launch_fused<S, false, true>(kp, ha, grid, stream) : launch_fused<S, false, false>(kp, ha, grid, stream);
 }
 
 template <int S>
-void launch_ident_s(const KParams& kp, bool avg, dim3 grid, hipStream_t stream) {
+void launch_ident_s(const KParams& kp, const OutArgs& oa, bool avg, dim3 grid, hipStream_t stream) {
   if (avg)
-    hipLaunchKernelGGL((vsl_ident_kernel<S, true>), grid, dim3(kIdNT), 0, stream, kp);
+    hipLaunchKernelGGL((vsl_ident_kernel<S, true>), grid, dim3(kIdNT), 0, stream, kp, oa);
   else
-    hipLaunchKernelGGL((vsl_ident_kernel<S, false>), grid, dim3(kIdNT), 0, stream, kp);
+    hipLaunchKernelGGL((vsl_ident_kernel<S, false>), grid, dim3(kIdNT), 0, stream, kp, oa);
 }
 
-void launch_ident(const KParams& kp, bool avg, dim3 grid, hipStream_t stream) {
+void launch_ident(const KParams& kp, const OutArgs& oa, bool avg, dim3 grid, hipStream_t stream) {
   switch (kp.S) {
-    case 1: launch_ident_s<1>(kp, avg, grid, stream); break;
-    case 2: launch_ident_s<2>(kp, avg, grid, stream); break;
-    case 3: launch_ident_s<3>(kp, avg, grid, stream); break;
-    default: launch_ident_s<4>(kp, avg, grid, stream); break;
+    case 1: launch_ident_s<1>(kp, oa, avg, grid, stream); break;
+    case 2: launch_ident_s<2>(kp, oa, avg, grid, stream); break;
+    case 3: launch_ident_s<3>(kp, oa, avg, grid, stream); break;
+    default: launch_ident_s<4>(kp, oa, avg, grid, stream); break;
   }
 }
 
@@ -679,13 +701,26 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
 #endif
   // per-image projection matrices, shared by all heads: written by the identity pass when there is one
   kp.prep = (float*)((char*)heads[0].workspace + L.off_prep);
+  // optional outputs (depth, sampling grids, warped frames): their pointers travel through a table in the workspace
+  OutArgs oa{};
+  oa.n_heads = n_heads;
+  bool any_out = false;
+  for (int h = 0; h < n_heads; ++h) {
+    oa.ptr[h][0] = heads[h].depth;
+    for (int s = 0; s < kMaxSrc; ++s) {
+      oa.ptr[h][1 + s] = s < d->S ? heads[h].sample[s] : nullptr;
+      oa.ptr[h][1 + kMaxSrc + s] = s < d->S ? heads[h].color[s] : nullptr;
+    }
+    for (int i = 0; i < kOutPtrs; ++i) any_out = any_out || oa.ptr[h][i] != nullptr;
+  }
+  kp.out_table = any_out ? (float**)((char*)heads[0].workspace + L.off_outs) : nullptr;
   if (automask && !d->identity_min) {  // computed once into the first head's workspace and read by every head
     kp.idmin = (float*)((char*)heads[0].workspace + L.off_idmin);
-    launch_ident(kp, avg, dim3(swizzled_grid(make_layout(d->B, d->H, d->W, kIdTH).blocks)), stream);
+    launch_ident(kp, oa, avg, dim3(swizzled_grid(make_layout(d->B, d->H, d->W, kIdTH).blocks)), stream);
   } else {
     if (automask) kp.idmin = const_cast<float*>(d->identity_min);
     hipLaunchKernelGGL(vsl_prep_kernel, dim3((d->B * kPrepStride + 255) / 256 > 64 ? 64 : (d->B * kPrepStride + 255) / 256), dim3(256), 0,
-                       stream, kp);
+                       stream, kp, oa);
   }
   int rc = VSL_OK;
   if (ev0) (void)hipEventRecord(ev0, stream);
@@ -802,7 +837,7 @@ int vsl_debug_fused_occupancy(int S, int avg) {
   int n = -1;
   auto q = [&](auto kern, int nt, size_t lds) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, nt, lds); };
 #define VSL_OCC(S_, A_)                                                                     \
-  q(vsl_fused_kernel<S_, A_>, tile_threads(fused_tile_h(S_, A_)),                            \
+  q(vsl_fused_kernel<S_, A_, false>, tile_threads(fused_tile_h(S_, A_)),                     \
     Fused<kTW, fused_tile_h(S_, A_), tile_threads(fused_tile_h(S_, A_)), S_, A_>::LDS_FLOATS * sizeof(float))
   switch (S * 2 + (avg ? 1 : 0)) {
     case 2: VSL_OCC(1, false); break;
@@ -891,7 +926,7 @@ int vsl_identity_min(const vsl_loss_desc* d, float* identity_min, void* stream_)
   KParams kp = base_params(d);
   kp.idmin = identity_min;
   const Layout L = make_layout(d->B, d->H, d->W, kIdTH);
-  launch_ident(kp, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0, dim3(swizzled_grid(L.blocks)), (hipStream_t)stream_);
+  launch_ident(kp, OutArgs{}, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0, dim3(swizzled_grid(L.blocks)), (hipStream_t)stream_);
   if (hipError_t e = hipGetLastError(); e != hipSuccess)
     return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return VSL_OK;

@@ -418,6 +418,99 @@ def warp_features(feats, disp, K, inv_K, T, min_depth=0.1, max_depth=100.0, eps=
     return (out, sample) if return_sample else out
 
 
+class _WarpMulti(torch.autograd.Function):
+    """Several feature maps through one set of sampling coordinates (vsl_warp_multi_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, n, min_depth, max_depth, eps, disp, K, inv_K, T, *feats):
+        feats = [_prep(f, "feats") for f in feats]
+        disp, K, inv_K, T = _prep(disp, "disp"), _prep(K, "K"), _prep(inv_K, "inv_K"), _prep(T, "T")
+        B, _, H, W = feats[0].shape
+        if any(f.dim() != 4 or f.shape[0] != B or tuple(f.shape[2:]) != (H, W) for f in feats) \
+                or tuple(disp.shape) != (B, 1, H, W):
+            raise ValueError("every feature map must be [B,C,H,W] and disp [B,1,H,W] of one size")
+        if any(tuple(m.shape) != (B, 4, 4) for m in (K, inv_K, T)):
+            raise ValueError("K, inv_K and T must be [B,4,4]")
+        d = _abi.WarpMultiDesc()
+        d.B, d.H, d.W, d.n = B, H, W, n
+        d.min_depth, d.max_depth, d.eps = float(min_depth), float(max_depth), float(eps)
+        outs = [torch.empty_like(f) for f in feats]
+        tab = (ctypes.c_void_p * _abi.MAX_WARP_TENSORS)()
+        for i, f in enumerate(feats):
+            d.C[i], d.feats[i], tab[i] = f.shape[1], f.data_ptr(), outs[i].data_ptr()
+        d.disp, d.K, d.inv_K, d.T = disp.data_ptr(), K.data_ptr(), inv_K.data_ptr(), T.data_ptr()
+        sample = torch.empty(B, H, W, 2, dtype=torch.float32, device=disp.device)
+        _abi.check(_lib.vsl_warp_multi_fwd(ctypes.byref(d), tab, sample.data_ptr(), _stream(disp)))
+        ctx.save_for_backward(disp, K, inv_K, T, *feats)
+        ctx.desc = d
+        ctx.mark_non_differentiable(sample)
+        return (sample,) + tuple(outs)
+
+    @staticmethod
+    def backward(ctx, _g_sample, *g_outs):
+        disp, K, inv_K, T = ctx.saved_tensors[:4]
+        feats = ctx.saved_tensors[4:]
+        d = ctx.desc
+        need = ctx.needs_input_grad          # (n, min, max, eps, disp, K, inv_K, T, *feats)
+        g_outs = [g.float().contiguous() if g is not None else None for g in g_outs]
+        g_feats = [torch.empty_like(f) if (need[8 + i] and g_outs[i] is not None) else None for i, f in enumerate(feats)]
+        if all(g is None for g in g_outs):
+            return (None,) * (8 + len(feats))
+        go, gf = (ctypes.c_void_p * _abi.MAX_WARP_TENSORS)(), (ctypes.c_void_p * _abi.MAX_WARP_TENSORS)()
+        for i in range(len(feats)):
+            go[i], gf[i] = _ptr(g_outs[i]), _ptr(g_feats[i])
+        g_disp = torch.empty_like(disp) if need[4] else None
+        g_T = torch.empty_like(T) if need[7] else None
+        nbytes = _lib.vsl_warp_multi_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=disp.device)
+        _abi.check(_lib.vsl_warp_multi_bwd(ctypes.byref(d), go, gf, _ptr(g_disp), _ptr(g_T), ws.data_ptr(), ws.numel() * 8,
+                                           _stream(disp)))
+        return (None, None, None, None, g_disp, None, None, g_T) + tuple(g_feats)
+
+
+def warp_features_multi(feats, disp, K, inv_K, T, min_depth=0.1, max_depth=100.0, eps=1e-7):
+    """``warp_features`` for 1..4 feature maps that share one sampling grid -- the colour frame and the 25-channel
+    affinity map of a source frame (Python/Trainer.py:467-473) -- in ONE launch.  Returns ``(sample, [warped...])``."""
+    feats = list(feats)
+    if not 1 <= len(feats) <= _abi.MAX_WARP_TENSORS:
+        raise ValueError("need 1..%d feature maps" % _abi.MAX_WARP_TENSORS)
+    res = _WarpMulti.apply(len(feats), min_depth, max_depth, eps, disp, K, inv_K, T, *feats)
+    return res[0], list(res[1:])
+
+
+class _AffinityLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, rand, keep_below):
+        pred, target, rand = _prep(pred, "pred"), _prep(target, "target"), _prep(rand, "rand")
+        if target.shape != pred.shape or rand.shape != pred.shape:
+            raise ValueError("pred, target and rand must have one shape")
+        n = pred.numel()
+        nbytes = _lib.vsl_affinity_loss_workspace_bytes(n)
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=pred.device)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        _abi.check(_lib.vsl_affinity_loss_fwd(pred.data_ptr(), target.data_ptr(), rand.data_ptr(), float(keep_below), n,
+                                              loss.data_ptr(), ws.data_ptr(), ws.numel() * 8, _stream(pred)))
+        ctx.save_for_backward(pred, target, rand)
+        ctx.keep_below = float(keep_below)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        pred, target, rand = ctx.saved_tensors
+        g_pred = torch.empty_like(pred)
+        g = g_loss.float().contiguous().reshape(1)
+        _abi.check(_lib.vsl_affinity_loss_bwd(pred.data_ptr(), target.data_ptr(), rand.data_ptr(), ctx.keep_below, pred.numel(),
+                                              g.data_ptr(), g_pred.data_ptr(), _stream(pred)))
+        return g_pred, None, None, None
+
+
+def affinity_reprojection_loss(pred, target, rand, keep_below=0.5):
+    """``Trainer.compute_affinity_reprojection_loss`` (Python/Trainer.py:497-516) as one forward and one backward
+    kernel: mean((pred - target * drop)**2), drop = pred where ``rand < keep_below`` else 1; ``rand`` is the
+    reference's ``torch.rand_like(target)``.  Differentiable with respect to ``pred``."""
+    return _AffinityLoss.apply(pred, target, rand, keep_below)
+
+
 # ------------------------------------------------------------------ depth metrics (Trainer.py:622-662, layers.py:265-283)
 def depth_metrics(depth, depth_gt, crop=(153, 371, 44, 1197), clamp=(1e-3, 80.0)):
     """The masked, median-scaled depth metrics of ``Trainer.compute_depth_losses`` in one stream-ordered call

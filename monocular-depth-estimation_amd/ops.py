@@ -57,17 +57,36 @@ class _FusedLossFn(torch.autograd.Function):
         automask = bool(cfg["flags"] & _abi.FLAG_AUTOMASK)
         ident = torch.empty(B, H, W, dtype=torch.float32, device=disp.device) if automask else None
         stream = torch.cuda.current_stream(disp.device).cuda_stream
-        _abi.check(_abi.lib.vsl_loss_forward(ctypes.byref(desc), ws.data_ptr(), nbytes, losses.data_ptr(),
-                                             ident.data_ptr() if ident is not None else None, stream))
+        extra = ()
+        if cfg.get("materialise"):
+            # the tensors Trainer.generate_images_pred keeps (Trainer.py:436,464,467), from the same launch
+            head = _abi.Head()
+            head.disp, head.workspace, head.workspace_bytes = desc.disp, ws.data_ptr(), nbytes
+            head.losses = losses.data_ptr()
+            head.identity_selection = ident.data_ptr() if ident is not None else None
+            head.n_scales = desc.n_scales
+            for i in range(desc.n_scales):
+                head.scale_weight[i] = desc.scale_weight[i]
+            depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=disp.device)
+            sample = torch.empty(S, B, H, W, 2, dtype=torch.float32, device=disp.device)
+            color = torch.empty(S, B, 3, H, W, dtype=torch.float32, device=disp.device)
+            head.depth = depth.data_ptr()
+            for s in range(S):
+                head.sample[s], head.color[s] = sample[s].data_ptr(), color[s].data_ptr()
+            _abi.check(_abi.lib.vsl_loss_forward_heads(ctypes.byref(desc), ctypes.byref(head), 1, stream))
+            extra = (depth, sample, color)
+        else:
+            _abi.check(_abi.lib.vsl_loss_forward(ctypes.byref(desc), ws.data_ptr(), nbytes, losses.data_ptr(),
+                                                 ident.data_ptr() if ident is not None else None, stream))
         ctx.desc, ctx.ws, ctx.nbytes, ctx.keep = desc, ws, nbytes, keep
         ctx.shape = (B, H, W, S)
         if ident is None:
             ident = torch.empty(0, device=disp.device)
-        ctx.mark_non_differentiable(ident)
-        return losses, ident
+        ctx.mark_non_differentiable(ident, *extra)
+        return (losses, ident) + extra
 
     @staticmethod
-    def backward(ctx, g_losses, _g_ident):
+    def backward(ctx, g_losses, _g_ident, *_g_extra):
         B, H, W, S = ctx.shape
         dev = ctx.ws.device
         need = ctx.needs_input_grad  # (cfg, disp, *poses)
@@ -91,13 +110,16 @@ def fused_view_synthesis_loss(disp: torch.Tensor, target: torch.Tensor, sources:
                               avg_reprojection: bool = False, no_ssim: bool = False,
                               scale_weights: Sequence[float] = (1e-3,), inv_num_scales: float = 1.0,
                               warp_scale: float = 1.0, min_depth: float = 0.1, max_depth: float = 100.0,
-                              seed: int = 0):
+                              seed: int = 0, materialise: bool = False):
     """One fused pass of the view-synthesis loss.
 
     disp [B,1,H,W]; target and every source [B,3,H,W]; K, inv_K and every pose [B,4,4].
     Returns ``(losses, identity_selection)``: ``losses`` is a float32 vector laid out as
     ``_abi.LOSS_*`` (total, photometric mean, smoothness, then one "loss/{scale}" per entry
     of ``scale_weights``); ``identity_selection`` is [B,H,W] (empty without auto-masking).
+    With ``materialise`` the same launch also writes what ``Trainer.generate_images_pred`` keeps
+    (Python/Trainer.py:436,464,467) and the call returns ``(losses, identity_selection, depth [B,1,H,W],
+    sample [S,B,H,W,2], color [S,B,3,H,W])``, the extra tensors detached.
     """
     if disp.dim() != 4 or disp.shape[1] != 1:
         raise ValueError("disp must be [B,1,H,W]")
@@ -122,9 +144,10 @@ def fused_view_synthesis_loss(disp: torch.Tensor, target: torch.Tensor, sources:
                warp_scale=float(warp_scale), scale_weights=[float(w) for w in scale_weights],
                inv_num_scales=float(inv_num_scales), target=_f32c(target, "target"),
                sources=[_f32c(s, "source") for s in sources], K=_f32c(K, "K"), inv_K=_f32c(inv_K, "inv_K"),
-               noise=_f32c(noise, "noise") if (noise is not None and automask) else None, seed=int(seed))
-    losses, ident = _FusedLossFn.apply(cfg, disp, *poses)
-    return losses, (ident if automask else None)
+               noise=_f32c(noise, "noise") if (noise is not None and automask) else None, seed=int(seed),
+               materialise=bool(materialise))
+    out = _FusedLossFn.apply(cfg, disp, *poses)
+    return (out[0], (out[1] if automask else None)) + tuple(out[2:])
 
 
 class _FusedHeadsFn(torch.autograd.Function):

@@ -28,8 +28,9 @@ import torch
 import torch.nn.functional as F
 
 from . import _abi
-from .layers import (BackprojectDepth, Project3D, SSIM, depth_metrics, disp_to_depth, get_smooth_loss,
-                     grid_sample_border, mean_inverse_depth, poses_from_parameters, warp_features)
+from .layers import (BackprojectDepth, Project3D, SSIM, affinity_reprojection_loss, depth_metrics, disp_to_depth,
+                     get_smooth_loss, grid_sample_border, mean_inverse_depth, poses_from_parameters, warp_features,
+                     warp_features_multi)
 from .ops import fused_view_synthesis_loss, fused_view_synthesis_loss_heads
 
 
@@ -103,13 +104,20 @@ class ViewSynthesisLoss:
         disp = self._full_res_disp(outputs)
         _, depth = disp_to_depth(disp, self.opt.min_depth, self.opt.max_depth)
         outputs[("depth", 0)] = depth
-        points = self.backproject_depth(depth, inputs["inv_K"])
+        affinity = self.use_affinity and not self.val_mode
+        points = None if affinity else self.backproject_depth(depth, inputs["inv_K"])
         for f, T in zip(self._sources(), self._poses(inputs, outputs, disp)):
-            grid = self.project_3d(points, inputs["K"], T)
-            outputs[("sample", f)] = grid
-            outputs[("color", f)] = grid_sample_border(inputs[("image", f)], grid)
-            if self.use_affinity and not self.val_mode:                      # Trainer.py:468-473
-                outputs[("pred_affinity", f)] = grid_sample_border(inputs[("affinity", f)][:, 0], grid)
+            if affinity:
+                # Trainer.py:467-473: the colour frame and the 25-channel affinity map of the source sampled with one
+                # grid -- one launch for both (coordinates from disp and T inside it, gradients to both)
+                grid, (color, aff) = warp_features_multi(
+                    [inputs[("image", f)].float(), inputs[("affinity", f)][:, 0].float()], disp, inputs["K"], inputs["inv_K"], T,
+                    self.opt.min_depth, self.opt.max_depth)
+                outputs[("sample", f)], outputs[("color", f)], outputs[("pred_affinity", f)] = grid, color, aff
+            else:
+                grid = self.project_3d(points, inputs["K"], T)
+                outputs[("sample", f)] = grid
+                outputs[("color", f)] = grid_sample_border(inputs[("image", f)], grid)
             if not self.opt.disable_automasking:
                 outputs[("color_identity", f)] = inputs[("image", f)]
 
@@ -125,13 +133,12 @@ class ViewSynthesisLoss:
     # ------------------------------------------------------------------ Trainer.py:497-516
     def compute_affinity_reprojection_loss(self, input_, t_seg, target, weight, rand: Optional[torch.Tensor] = None):
         """Squared error between the warped affinity map and the target frame's, the target multiplied by the
-        prediction where ``rand < weight[1]``; ``t_seg`` does not enter the value (Trainer.py:508-514).  Six
-        elementwise torch ops on the device; the 25-channel gather before it is the HIP part."""
+        prediction where ``rand < weight[1]``; ``t_seg`` does not enter the value (Trainer.py:508-514).  One
+        forward and one backward kernel (vsl_affinity_loss_fwd / _bwd); ``rand`` is the reference's
+        ``torch.rand_like(target)`` (drawn here when not given)."""
         target = target.float().to(input_.device)
-        rand = torch.rand_like(target) if rand is None else rand.to(input_.device)
-        keep = (rand < weight[1]).float()
-        drop = torch.where(keep == 1.0, input_, torch.ones_like(target))
-        return torch.mean((input_ - target * drop) ** 2)
+        rand = torch.rand_like(target) if rand is None else rand.float().to(input_.device)
+        return affinity_reprojection_loss(input_, target, rand, float(weight[1]))
 
     # ------------------------------------------------------------------ Trainer_distilation.py:1076-1110
     def compute_affinity_huber_loss(self, input_, t_seg, target, weight=None):
@@ -158,7 +165,10 @@ class ViewSynthesisLoss:
     # ------------------------------------------------------------------ Trainer.py:518-620
     def compute_losses(self, inputs: Dict, outputs: Dict, noise: Optional[torch.Tensor] = None,
                        photometric_scale: Optional[float] = None,
-                       drop_rand: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                       drop_rand: Optional[torch.Tensor] = None, materialise: bool = False) -> Dict[str, torch.Tensor]:
+        """``materialise``: the same launch also fills outputs[("depth",0)], ("sample",f), ("color",f) and
+        ("color_identity",f) -- what generate_images_pred leaves for validation dumps and the depth metrics
+        (Trainer.py:129-132,627) -- so that no second pass over the per-module kernels is needed (detached)."""
         opt = self.opt
         srcs = self._sources()
         disp = self._full_res_disp(outputs)
@@ -166,13 +176,20 @@ class ViewSynthesisLoss:
         scale_w = [opt.disparity_smoothness / (2 ** s) for s in opt.scales]
         self._step += 1
         poses = self._poses(inputs, outputs, disp)
-        out, ident = fused_view_synthesis_loss(
+        res = fused_view_synthesis_loss(
             disp, inputs[("image", 0)], [inputs[("image", f)] for f in srcs], inputs["K"], inputs["inv_K"],
             poses, noise,
             automask=automask, avg_reprojection=opt.avg_reprojection, no_ssim=opt.no_ssim,
             scale_weights=scale_w, inv_num_scales=1.0 / self.num_scales,
             warp_scale=self.photometric_scale if photometric_scale is None else photometric_scale,
-            min_depth=opt.min_depth, max_depth=opt.max_depth, seed=self.seed + self._step)
+            min_depth=opt.min_depth, max_depth=opt.max_depth, seed=self.seed + self._step, materialise=materialise)
+        out, ident = res[0], res[1]
+        if materialise:
+            outputs[("depth", 0)] = res[2]
+            for i, f in enumerate(srcs):
+                outputs[("sample", f)], outputs[("color", f)] = res[3][i], res[4][i]
+                if automask:
+                    outputs[("color_identity", f)] = inputs[("image", f)]
         if automask:
             outputs["identity_selection"] = ident
         losses = {"loss/{}".format(s): out[_abi.LOSS_SCALE0 + i] for i, s in enumerate(opt.scales)}

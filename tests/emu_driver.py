@@ -40,7 +40,7 @@ class KParams(ctypes.Structure):
         ("noise", ctypes.c_void_p), ("seed", ctypes.c_ulonglong), ("idmin", ctypes.c_void_p),
         ("gphoto", ctypes.c_void_p), ("gedge", ctypes.c_void_p), ("ident_sel", ctypes.c_void_p),
         ("partials", ctypes.c_void_p), ("counter", ctypes.c_void_p), ("prep", ctypes.c_void_p),
-        ("want_grad", ctypes.c_int),
+        ("want_grad", ctypes.c_int), ("out_table", ctypes.c_void_p),
     ]
 
 

@@ -24,7 +24,7 @@ def test_descriptor_mirror_and_workspace_query():
     import mde_amd._abi as abi
     d = abi.LossDesc()
     assert ctypes.sizeof(d) == 208
-    assert ctypes.sizeof(abi.Head) == 128
+    assert ctypes.sizeof(abi.Head) == 200
     d.B, d.H, d.W, d.S = 12, 192, 640, 2
     n = abi.lib.vsl_loss_workspace_bytes(ctypes.byref(d))
     assert n >= 2 * 12 * 192 * 640 * 4 and n % 256 == 0

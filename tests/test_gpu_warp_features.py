@@ -195,3 +195,80 @@ def test_affinity_huber_variant_matches_reference_fixture():
     assert abs(float(loss) - float(z["loss"])) <= TOL * abs(float(z["loss"]))
     e = rel(pred.grad, z["grad_pred"])
     assert e <= TOL, "grad %.2e" % e
+
+
+def test_colour_and_affinity_in_one_launch_match_fixture_and_separate_calls():
+    """generate_images_pred with the affinity term on (Python/Trainer.py:467-473): the colour frame (3 channels) and
+    the affinity map (25 channels) of a source frame go through ONE launch that shares the sampling coordinates;
+    values against the reference fixture and, bit for bit, against one single-tensor launch per map; gradients of
+    a loss over both outputs against the sum of the separate launches' gradients."""
+    import json
+    import types
+    from mde_amd.layers import warp_features, warp_features_multi
+    from mde_amd.trainer_loss import ViewSynthesisLoss
+    z = np.load(os.path.join(GOLDEN_DIR, "affinity", "b2_24x80_affinity.npz"), allow_pickle=False)
+    c = json.loads(str(z["config"]))
+    fids = c["frame_ids"]
+    t = lambda k: torch.from_numpy(z[k]).to(DEV)
+    K, inv_K = t("K"), t("inv_K")
+    f = fids[1]
+    img, aff = t("image_%s" % f).float(), t("affinity_%s" % f)[:, 0].float()
+    disp = t("disp").requires_grad_(True)
+    T = t("T_%s" % f).requires_grad_(True)
+    grid, (color, paff) = warp_features_multi([img, aff], disp, K, inv_K, T)
+    assert rel(paff, z["pred_affinity_%s" % f]) <= TOL
+    w1 = torch.linspace(0.5, 1.5, color.numel(), device=DEV).view_as(color)
+    w2 = torch.linspace(-1.0, 1.0, paff.numel(), device=DEV).view_as(paff)
+    ((color * w1).sum() + (paff * w2).sum()).backward()
+    g_disp, g_T = disp.grad.clone(), T.grad.clone()
+    disp.grad = T.grad = None
+    color1, grid1 = warp_features(img, disp, K, inv_K, T, return_sample=True)
+    paff1 = warp_features(aff, disp, K, inv_K, T)
+    assert torch.equal(grid, grid1) and torch.equal(color, color1) and torch.equal(paff, paff1)
+    ((color1 * w1).sum() + (paff1 * w2).sum()).backward()
+    # (one chain through the projection for the summed tap derivatives against two chains summed afterwards: float32 order)
+    assert rel(g_disp, disp.grad.cpu().numpy()) <= TOL and rel(g_T, T.grad.cpu().numpy()) <= TOL
+    # only one of the two outputs carries a gradient: the other tensor's groups contribute nothing
+    disp.grad = T.grad = None
+    _, (color2, paff2) = warp_features_multi([img, aff], disp, K, inv_K, T)
+    (paff2 * w2).sum().backward()
+    ga = disp.grad.clone()
+    disp.grad = T.grad = None
+    (warp_features(aff, disp, K, inv_K, T) * w2).sum().backward()
+    assert torch.equal(ga, disp.grad)
+    # the trainer surface: ("color",f), ("sample",f), ("pred_affinity",f) of every source from one launch each
+    opt = types.SimpleNamespace(scales=c["scales"], frame_ids=fids, height=c["H"], width=c["W"], min_depth=0.1,
+                                max_depth=100.0, v1_multiscale=False, disable_automasking=False, avg_reprojection=False,
+                                no_ssim=False, disparity_smoothness=1e-3)
+    vs = ViewSynthesisLoss(opt, use_affinity=True)
+    inputs = {"K": K, "inv_K": inv_K}
+    outputs = {("disp", 0): t("disp")}
+    for g in fids:
+        inputs[("image", g)], inputs[("affinity", g)] = t("image_%s" % g), t("affinity_%s" % g)
+    for g in fids[1:]:
+        outputs[("cam_T_cam", g)] = t("T_%s" % g)
+    vs.generate_images_pred(inputs, outputs)
+    for g in fids[1:]:
+        assert rel(outputs[("pred_affinity", g)], z["pred_affinity_%s" % g]) <= TOL
+        assert tuple(outputs[("color", g)].shape) == tuple(inputs[("image", g)].shape)
+
+
+def test_affinity_loss_kernel_matches_torch_ops_and_fixture():
+    """vsl_affinity_loss_fwd / _bwd against the reference's op sequence (Python/Trainer.py:497-516) on the fixture's
+    warped map, target map and pinned torch.rand_like tensor: value and gradient with respect to the prediction."""
+    from mde_amd.layers import affinity_reprojection_loss
+    z = np.load(os.path.join(GOLDEN_DIR, "affinity", "b2_24x80_affinity.npz"), allow_pickle=False)
+    pred = torch.from_numpy(z["pred_affinity_-1"]).float().to(DEV).requires_grad_(True)
+    target = torch.from_numpy(z["affinity_0"])[:, 0].float().to(DEV)
+    rand = torch.from_numpy(z["drop_rand"]).float().to(DEV)
+    loss = affinity_reprojection_loss(pred, target, rand, 0.5)
+    (3.0 * loss).backward()
+    ref_pred = pred.detach().double().requires_grad_(True)
+    keep = (rand.double() < 0.5).double()
+    drop = torch.where(keep == 1.0, ref_pred, torch.ones_like(ref_pred))
+    ref = torch.mean((ref_pred - target.double() * drop) ** 2)
+    (3.0 * ref).backward()
+    assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
+    assert rel(pred.grad, ref_pred.grad.cpu().numpy()) <= 1e-6
+    again = affinity_reprojection_loss(pred.detach(), target, rand, 0.5)
+    assert again.item() == loss.item()                       # deterministic
