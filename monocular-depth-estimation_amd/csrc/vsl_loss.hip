@@ -107,6 +107,7 @@ struct HeadArgs {
   unsigned int* counter[VSL_MAX_HEADS];
   float cst_ssim[VSL_MAX_HEADS], cst_l1[VSL_MAX_HEADS];
   int want_grad[VSL_MAX_HEADS];
+  int index[VSL_MAX_HEADS];  // the head's position in the caller's table (a launch may cover a subset of the heads)
 };
 
 template <int S, bool AVG, bool OUT>
@@ -124,7 +125,7 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   // the head's pointers and constants (a patched copy of the argument struct would end up in scratch memory)
   const HeadView hv{ha.disp[head],     ha.gphoto[head],  ha.gedge[head],    ha.ident_sel[head],
                     ha.partials[head], ha.counter[head], ha.cst_ssim[head], ha.cst_l1[head],
-                    ha.want_grad[head], head};
+                    ha.want_grad[head], ha.index[head]};
 
   ThreadState<S> st;
 #ifdef VSL_STAMPS
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG))) void vsl_forwar
   const KParams& kp = kp_in;
   const HeadView hv{ha.disp[head],     ha.gphoto[head],  ha.gedge[head],    ha.ident_sel[head],
                     ha.partials[head], ha.counter[head], ha.cst_ssim[head], ha.cst_l1[head],
-                    0, head};
+                    0, ha.index[head]};
   ThreadState<S> st;
   F::phase0(kp, hv, bk, tid, st);
   F::phase1(kp, hv, bk, tid, lds, st);
@@ -674,6 +675,7 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
     ha.cst_ssim[h] = no_ssim ? 0.0f : (float)(base * d->ssim_weight / 27.0);
     ha.cst_l1[h] = no_ssim ? (float)(base / 3.0) : (float)(base * d->l1_weight / 3.0);
     ha.want_grad[h] = want_grad && !(hd.flags & VSL_HEAD_NO_GRAD);
+    ha.index[h] = h;
     FinalizeHead& fh = fp.head[h];
     fh.n_scales = hd.n_scales;
     for (int i = 0; i < VSL_MAX_SCALES; ++i) fh.scale_weight[i] = i < hd.n_scales ? hd.scale_weight[i] : 0.0f;
@@ -687,7 +689,6 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
     fh.losses = hd.losses;
   }
 
-  const dim3 grid(swizzled_grid(L.blocks * n_heads));
 #ifdef VSL_STAMPS
   {
     const size_t need = (size_t)L.blocks * n_heads * 8 * 16 * sizeof(unsigned long long);
@@ -724,21 +725,40 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
   }
   int rc = VSL_OK;
   if (ev0) (void)hipEventRecord(ev0, stream);
-  bool any_grad = false;
-  for (int h = 0; h < n_heads; ++h) any_grad = any_grad || ha.want_grad[h] != 0;
-  if (any_grad) {
+  // Heads with gradients go through the full tile program, forward-only heads (a teacher head beside a student's)
+  // through the forward-only one (halo 1, no coefficient planes: about half the time per head): two grids when
+  // a call has both kinds.
+  HeadArgs hg{}, hf{};
+  auto take = [&](HeadArgs& dst, int h) {
+    const int i = dst.n_heads++;
+    dst.disp[i] = ha.disp[h];
+    dst.gphoto[i] = ha.gphoto[h];
+    dst.gedge[i] = ha.gedge[h];
+    dst.ident_sel[i] = ha.ident_sel[h];
+    dst.partials[i] = ha.partials[h];
+    dst.counter[i] = ha.counter[h];
+    dst.cst_ssim[i] = ha.cst_ssim[h];
+    dst.cst_l1[i] = ha.cst_l1[h];
+    dst.want_grad[i] = ha.want_grad[h];
+    dst.index[i] = h;
+  };
+  for (int h = 0; h < n_heads; ++h) take(ha.want_grad[h] ? hg : hf, h);
+  if (hg.n_heads) {
+    const dim3 gg(swizzled_grid(L.blocks * hg.n_heads));
     switch (d->S) {
-      case 1: rc = launch_fused_s<1>(kp, ha, avg, grid, stream); break;
-      case 2: rc = launch_fused_s<2>(kp, ha, avg, grid, stream); break;
-      case 3: rc = launch_fused_s<3>(kp, ha, avg, grid, stream); break;
-      default: rc = launch_fused_s<4>(kp, ha, avg, grid, stream); break;
+      case 1: rc = launch_fused_s<1>(kp, hg, avg, gg, stream); break;
+      case 2: rc = launch_fused_s<2>(kp, hg, avg, gg, stream); break;
+      case 3: rc = launch_fused_s<3>(kp, hg, avg, gg, stream); break;
+      default: rc = launch_fused_s<4>(kp, hg, avg, gg, stream); break;
     }
-  } else {  // no head wants gradients: the forward-only tile program (halo 1, no coefficient planes)
+  }
+  if (hf.n_heads && rc == VSL_OK) {
+    const dim3 gf(swizzled_grid(L.blocks * hf.n_heads));
     switch (d->S) {
-      case 1: launch_forward_s<1>(kp, ha, avg, grid, stream); break;
-      case 2: launch_forward_s<2>(kp, ha, avg, grid, stream); break;
-      case 3: launch_forward_s<3>(kp, ha, avg, grid, stream); break;
-      default: launch_forward_s<4>(kp, ha, avg, grid, stream); break;
+      case 1: launch_forward_s<1>(kp, hf, avg, gf, stream); break;
+      case 2: launch_forward_s<2>(kp, hf, avg, gf, stream); break;
+      case 3: launch_forward_s<3>(kp, hf, avg, gf, stream); break;
+      default: launch_forward_s<4>(kp, hf, avg, gf, stream); break;
     }
   }
   if (ev1) (void)hipEventRecord(ev1, stream);

@@ -162,7 +162,8 @@ def test_process_batch_with_image_fed_pose_networks(kind, mode):
 
 def test_train_step_under_ddp_rccl_world_size_one():
     """RCCL initialisation and DistributedDataParallel's gradient hooks around the custom autograd.Function on the
-    real device: one rank, backend "nccl", three optimizer steps; losses equal the un-wrapped run bit for bit."""
+    real device: one rank, backend "nccl", three optimizer steps; losses equal the un-wrapped run (to 1e-6: the
+    convolution backward of the stand-in networks is not bit-reproducible from run to run)."""
     import torch.distributed as td
     from mde_amd.trainer_step import NetworkPass, TrainStep
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -182,4 +183,4 @@ def test_train_step_under_ddp_rccl_world_size_one():
             if wrap:
                 td.destroy_process_group()
     assert all(np.isfinite(runs[1])) and runs[1][-1] < runs[1][0]
-    assert runs[0] == runs[1]
+    assert runs[0][0] == runs[1][0] and np.allclose(runs[0], runs[1], rtol=1e-6, atol=0)
