@@ -73,6 +73,12 @@ constexpr int kTileW = 28, kIdentTileH = 12;
 #define VSL_TILE_H3 12
 #endif
 constexpr int fused_tile_h(int S, bool avg) { return (S <= 2 && !avg) ? VSL_TILE_H : VSL_TILE_H3; }
+// Tile width of the fused programs.  Three sources need 13 planes over R2: at 28 columns the LDS of a workgroup is
+// 42.4 KiB and three workgroups fit a CU, at 26 columns it is 39.7 KiB and four fit.
+#ifndef VSL_TILE_W3
+#define VSL_TILE_W3 26
+#endif
+constexpr int fused_tile_w(int S, bool avg) { return (S == 3 && !avg) ? VSL_TILE_W3 : kTileW; }
 constexpr int tile_threads(int th) { return 16 * (th + 4); }
 constexpr float kC1 = 0.01f * 0.01f;
 constexpr float kC2 = 0.03f * 0.03f;
@@ -685,11 +691,20 @@ struct Fused {
   // row pitch = 8 mod 64: the (row, piece) items of a wave in phase4_sum_a then read 64 different banks
   static constexpr int RED_PITCH = ((NT + 63) / 64) * 64 + 8;
   static constexpr int NRED = HALO == 2 ? NPART : 4;  // partial sums that can be non-zero
-  static constexpr int RED_FLOATS = NRED * RED_PITCH;
   static constexpr int RED_SPLIT = 8;
+  // Full program: a sum only has entries where they can be non-zero.  The photometric sum and the 12 gradient sums
+  // per source are held by the threads of the tile rows (BIG = ROWP x TH entries; the photometric one by thread rows
+  // 1..TH, which took the interior rows of R1 in phase 2), the three smoothness sums by the threads beyond them
+  // (SMALL entries).  Pitches = 8 mod 64 floats, so that the items of a wave in phase4_sum_a read 64 different banks.
+  // With three sources this is what lets the planes, not the reduction, set the LDS footprint (four workgroups per CU).
+  static constexpr int NBIG = 1 + 12 * S;
+  static constexpr int BIG = ROWP * TH, SMALL = NT - ROWP * TH;
+  static constexpr int BIG_PITCH = ((BIG + 63) / 64) * 64 + 8, SMALL_PITCH = ((SMALL + 63) / 64) * 64 + 8;
+  static constexpr int RED_FLOATS = HALO == 2 ? NBIG * BIG_PITCH + 3 * SMALL_PITCH : NRED * RED_PITCH;
   static constexpr int LDS_MAIN = OFF_COEF + COEF_FLOATS;
-  static constexpr int RED_TOTAL = RED_FLOATS + NRED * RED_SPLIT;
+  static constexpr int RED_TOTAL = RED_FLOATS + (HALO == 2 ? NBIG + 3 : NRED) * RED_SPLIT;
   static constexpr int LDS_FLOATS = LDS_MAIN > RED_TOTAL ? LDS_MAIN : RED_TOTAL;
+  static_assert(HALO == 1 || (SMALL > 0 && SMALL % ROWP == 0 && BIG % ROWP == 0), "the full program needs threads beside the tile rows");
 
   struct Block {
     int b, x0, y0;
@@ -744,7 +759,15 @@ struct Fused {
   static VSL_DEV void phase1(const KParams& kp, const HeadView& hv, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
     st.photo = 0.0f;
     const int trow = tid / ROWP, rx0 = 2 * (tid % ROWP);
-    if (trow >= R2H || rx0 >= R2W) return;
+    if (trow >= R2H || rx0 >= R2W) {
+      // No position for this thread (regions narrower than 2 * ROWP columns).  Phase 3 keeps every lane of a tile row
+      // alive for its lane exchange and lets it fetch the taps its record names: the record must name a valid texel.
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int s = 0; s < S; ++s) st.ch[k][s] = Chain{0.0f, 0.0f, 0};
+      return;
+    }
     // Full program: thread row t warps R2 row t + 2 (wrapping round), so that thread rows 0..TH-1 -- whole waves --
     // hold the tap records of the interior rows, which the same threads differentiate in phase 3, and the halo
     // rows fall to the last wave, which phase 3 gives the smoothness term instead.
@@ -1423,11 +1446,38 @@ struct Fused {
 
   // ---- phase 4: deterministic block reduction ----------------------------------
   static VSL_DEV void phase4_store(int tid, float* lds, const ThreadState<S>& st) {
+    if constexpr (HALO == 2) {
+      const int trow = tid / ROWP;
+      if (trow >= 1 && trow <= TH) lds[tid - ROWP] = st.part[0];
+      if (trow < TH) {
 #pragma unroll
-    for (int k = 0; k < NRED; ++k) lds[k * RED_PITCH + tid] = st.part[k];
+        for (int i = 1; i < NBIG; ++i) lds[i * BIG_PITCH + tid] = st.part[3 + i];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) lds[NBIG * BIG_PITCH + j * SMALL_PITCH + tid - BIG] = st.part[1 + j];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NRED; ++k) lds[k * RED_PITCH + tid] = st.part[k];
+    }
   }
   // after a barrier: item (row, part) sums every RED_SPLIT-th element of a row in a fixed order
   static VSL_DEV void phase4_sum_a(int tid, float* lds) {
+    if constexpr (HALO == 2) {
+      // pairs 0..7 of every thread row into one accumulator, pairs 8..15 into another, rows in ascending order
+      for (int item = tid; item < (NBIG + 3) * RED_SPLIT; item += NT) {
+        const int r = item / RED_SPLIT, part = item % RED_SPLIT;
+        const float* e = lds + (r < NBIG ? r * BIG_PITCH : NBIG * BIG_PITCH + (r - NBIG) * SMALL_PITCH) + part;
+        const int rows = r < NBIG ? BIG / ROWP : SMALL / ROWP;
+        float s0 = 0.0f, s1 = 0.0f;
+        for (int m = 0; m < rows; ++m) {
+          s0 += e[m * ROWP];
+          s1 += e[m * ROWP + RED_SPLIT];
+        }
+        lds[RED_FLOATS + item] = s0 + s1;
+      }
+      return;
+    }
     for (int item = tid; item < NRED * RED_SPLIT; item += NT) {
       const int row = item / RED_SPLIT, part = item % RED_SPLIT;
       const float* r = lds + row * RED_PITCH;
@@ -1441,12 +1491,18 @@ struct Fused {
       lds[RED_FLOATS + item] = s0 + s1;
     }
   }
-  // after another barrier: thread k < NPART adds the RED_SPLIT pieces of row k (rows that cannot be
+  // after another barrier: thread k < NPART adds the RED_SPLIT pieces of sum k (sums that cannot be
   // non-zero in the forward-only program are written as zeros: the finalize kernel reads all of them)
   static VSL_DEV void phase4_sum_b(const HeadView& hv, int block_linear, int tid, const float* lds) {
     if (tid >= NPART) return;
     float s = 0.0f;
-    if (tid < NRED) {
+    if constexpr (HALO == 2) {
+      // sum k: 0 photometric, 1..3 smoothness, 4.. gradient sums
+      const int r = tid == 0 ? 0 : (tid < 4 ? NBIG + tid - 1 : tid - 3);
+      const float* p = lds + RED_FLOATS + r * RED_SPLIT;
+#pragma unroll
+      for (int i = 0; i < RED_SPLIT; ++i) s += p[i];
+    } else if (tid < NRED) {
       const float* r = lds + RED_FLOATS + tid * RED_SPLIT;
 #pragma unroll
       for (int i = 0; i < RED_SPLIT; ++i) s += r[i];

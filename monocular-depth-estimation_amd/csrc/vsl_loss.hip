@@ -39,7 +39,7 @@ constexpr int kIdTH = kIdentTileH, kIdNT = tile_threads(kIdentTileH);
 template <int S, bool AVG>
 constexpr int fused_blocks_per_cu() {
   constexpr int TH = fused_tile_h(S, AVG);
-  constexpr int by_lds = 160 * 1024 / (Fused<kTW, TH, tile_threads(TH), S, AVG>::LDS_FLOATS * (int)sizeof(float));
+  constexpr int by_lds = 160 * 1024 / (Fused<fused_tile_w(S, AVG), TH, tile_threads(TH), S, AVG>::LDS_FLOATS * (int)sizeof(float));
   return by_lds > 5 ? 5 : by_lds;
 }
 
@@ -73,9 +73,9 @@ size_t g_stamp_bytes = 0;
 // (x fastest, then y, then image): horizontally and vertically adjacent tiles, which share 128-byte lines
 // of the images (a 28-pixel tile row is 112 bytes), then meet in the same L2 at about the same time.
 // Returns the tile's linear index (x fastest), or -1 for the padding workgroups past the last tile.
-template <int TH>
+template <int TH, int TW>
 __device__ __forceinline__ int swizzled_tile(const KParams& kp, int n_heads, int& head, int& b, int& x0, int& y0) {
-  const int tiles_x = (kp.W + kTW - 1) / kTW, tiles_y = (kp.H + TH - 1) / TH;
+  const int tiles_x = (kp.W + TW - 1) / TW, tiles_y = (kp.H + TH - 1) / TH;
   const int per_image = tiles_x * tiles_y;
   const int per_head = per_image * kp.B;
   const int chunk = (int)(gridDim.x >> 3);
@@ -90,7 +90,7 @@ __device__ __forceinline__ int swizzled_tile(const KParams& kp, int n_heads, int
   b = t / per_image;
   const int r = t - b * per_image;
   const int ty = r / tiles_x;
-  x0 = (r - ty * tiles_x) * kTW;
+  x0 = (r - ty * tiles_x) * TW;
   y0 = ty * TH;
   return t;
 }
@@ -114,12 +114,13 @@ template <int S, bool AVG, bool OUT>
 __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG)), (fused_blocks_per_cu<S, AVG>()))
 void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
-  using F = Fused<kTW, TH, NT, S, AVG, 2, OUT>;
+  constexpr int TW = fused_tile_w(S, AVG);
+  using F = Fused<TW, TH, NT, S, AVG, 2, OUT>;
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x;
   typename F::Block bk;
   int head = 0;
-  const int block_linear = swizzled_tile<TH>(kp_in, ha.n_heads, head, bk.b, bk.x0, bk.y0);
+  const int block_linear = swizzled_tile<TH, TW>(kp_in, ha.n_heads, head, bk.b, bk.x0, bk.y0);
   if (block_linear < 0) return;
   const KParams& kp = kp_in;
   // the head's pointers and constants (a patched copy of the argument struct would end up in scratch memory)
@@ -172,12 +173,13 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
 template <int S, bool AVG, bool OUT>
 __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG))) void vsl_forward_kernel(const KParams kp_in, const HeadArgs ha) {
   constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
-  using F = Fused<kTW, TH, NT, S, AVG, 1, OUT>;
+  constexpr int TW = fused_tile_w(S, AVG);
+  using F = Fused<TW, TH, NT, S, AVG, 1, OUT>;
   __shared__ __align__(16) float lds[F::LDS_FLOATS];
   const int tid = threadIdx.x;
   typename F::Block bk;
   int head = 0;
-  const int block_linear = swizzled_tile<TH>(kp_in, ha.n_heads, head, bk.b, bk.x0, bk.y0);
+  const int block_linear = swizzled_tile<TH, TW>(kp_in, ha.n_heads, head, bk.b, bk.x0, bk.y0);
   if (block_linear < 0) return;
   const KParams& kp = kp_in;
   const HeadView hv{ha.disp[head],     ha.gphoto[head],  ha.gedge[head],    ha.ident_sel[head],
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kIdNT) void vsl_ident_kernel(const KParams kp, cons
   if (blockIdx.x == 0) store_out_table(kp, oa, threadIdx.x, kIdNT);
   if (kp.prep && blockIdx.x == 0)
     for (int i = threadIdx.x; i < kp.B * kPrepStride; i += kIdNT) kp.prep[i] = prep_entry(kp, i / kPrepStride, i % kPrepStride);
-  if (swizzled_tile<kIdTH>(kp, 1, head, bk.b, bk.x0, bk.y0) < 0) return;
+  if (swizzled_tile<kIdTH, kTW>(kp, 1, head, bk.b, bk.x0, bk.y0) < 0) return;
   I::load(kp, bk, threadIdx.x, lds);
   __syncthreads();
   I::compute(kp, bk, threadIdx.x, lds);
@@ -452,10 +454,13 @@ struct Layout {
 inline int desc_tile_h(const vsl_loss_desc* d) {
   return fused_tile_h(d->S, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0);
 }
+inline int desc_tile_w(const vsl_loss_desc* d) {
+  return fused_tile_w(d->S, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0);
+}
 
-Layout make_layout(int B, int H, int W, int th) {
+Layout make_layout(int B, int H, int W, int th, int tw) {
   Layout L;
-  L.tiles_x = (W + kTW - 1) / kTW;
+  L.tiles_x = (W + tw - 1) / tw;
   L.tiles_y = (H + th - 1) / th;
   L.tiles_per_image = L.tiles_x * L.tiles_y;
   L.blocks = L.tiles_per_image * B;
@@ -504,7 +509,7 @@ int check_desc(const vsl_loss_desc* d) {
 template <int S, bool AVG, bool OUT>
 int launch_fused(const KParams& kp, const HeadArgs& ha, dim3 grid, hipStream_t stream) {
   constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
-  using F = Fused<kTW, TH, NT, S, AVG>;
+  using F = Fused<fused_tile_w(S, AVG), TH, NT, S, AVG>;
   constexpr size_t lds_bytes = (size_t)F::LDS_FLOATS * sizeof(float);
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit the 160 KiB LDS of a CU");
   // the attribute belongs to the (function, device) pair: remember it per device of the calling thread
@@ -596,7 +601,7 @@ int vsl_version(void) { return 100; }
 
 size_t vsl_loss_workspace_bytes(const vsl_loss_desc* d) {
   if (!d || d->B < 1 || d->H < 1 || d->W < 1) return 0;
-  return make_layout(d->B, d->H, d->W, desc_tile_h(d)).total;
+  return make_layout(d->B, d->H, d->W, desc_tile_h(d), desc_tile_w(d)).total;
 }
 
 }  // extern "C"
@@ -605,7 +610,7 @@ namespace {
 
 int check_heads(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, bool backward) {
   if (!heads || n_heads < 1 || n_heads > VSL_MAX_HEADS) return fail(VSL_ERR_INVALID_ARGUMENT, "need 1..VSL_MAX_HEADS heads");
-  const size_t need = make_layout(d->B, d->H, d->W, desc_tile_h(d)).total;
+  const size_t need = make_layout(d->B, d->H, d->W, desc_tile_h(d), desc_tile_w(d)).total;
   for (int h = 0; h < n_heads; ++h) {
     const vsl_head& hd = heads[h];
     if (hd.n_scales < 1 || hd.n_scales > VSL_MAX_SCALES) return fail(VSL_ERR_INVALID_ARGUMENT, "n_scales must be 1..VSL_MAX_SCALES");
@@ -628,7 +633,7 @@ void head_weights(const vsl_loss_desc* d, const vsl_head& hd, float& photo_w, fl
 int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, void* stream_, hipEvent_t ev0, hipEvent_t ev1) {
   if (int rc = check_desc(d)) return rc;
   if (int rc = check_heads(d, heads, n_heads, false)) return rc;
-  const Layout L = make_layout(d->B, d->H, d->W, desc_tile_h(d));
+  const Layout L = make_layout(d->B, d->H, d->W, desc_tile_h(d), desc_tile_w(d));
   hipStream_t stream = (hipStream_t)stream_;
 
   const bool avg = (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0;
@@ -717,7 +722,7 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
   kp.out_table = any_out ? (float**)((char*)heads[0].workspace + L.off_outs) : nullptr;
   if (automask && !d->identity_min) {  // computed once into the first head's workspace and read by every head
     kp.idmin = (float*)((char*)heads[0].workspace + L.off_idmin);
-    launch_ident(kp, oa, avg, dim3(swizzled_grid(make_layout(d->B, d->H, d->W, kIdTH).blocks)), stream);
+    launch_ident(kp, oa, avg, dim3(swizzled_grid(make_layout(d->B, d->H, d->W, kIdTH, kTW).blocks)), stream);
   } else {
     if (automask) kp.idmin = const_cast<float*>(d->identity_min);
     hipLaunchKernelGGL(vsl_prep_kernel, dim3((d->B * kPrepStride + 255) / 256 > 64 ? 64 : (d->B * kPrepStride + 255) / 256), dim3(256), 0,
@@ -774,7 +779,7 @@ int backward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, vo
   if (int rc = check_desc(d)) return rc;
   if (d->flags & VSL_FLAG_NO_GRAD) return fail(VSL_ERR_INVALID_ARGUMENT, "forward ran with VSL_FLAG_NO_GRAD");
   if (int rc = check_heads(d, heads, n_heads, true)) return rc;
-  const Layout L = make_layout(d->B, d->H, d->W, desc_tile_h(d));
+  const Layout L = make_layout(d->B, d->H, d->W, desc_tile_h(d), desc_tile_w(d));
   GradParams gp{};
   gp.B = d->B;
   gp.HW = d->H * d->W;
@@ -858,7 +863,7 @@ int vsl_debug_fused_occupancy(int S, int avg) {
   auto q = [&](auto kern, int nt, size_t lds) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, nt, lds); };
 #define VSL_OCC(S_, A_)                                                                     \
   q(vsl_fused_kernel<S_, A_, false>, tile_threads(fused_tile_h(S_, A_)),                     \
-    Fused<kTW, fused_tile_h(S_, A_), tile_threads(fused_tile_h(S_, A_)), S_, A_>::LDS_FLOATS * sizeof(float))
+    Fused<fused_tile_w(S_, A_), fused_tile_h(S_, A_), tile_threads(fused_tile_h(S_, A_)), S_, A_>::LDS_FLOATS * sizeof(float))
   switch (S * 2 + (avg ? 1 : 0)) {
     case 2: VSL_OCC(1, false); break;
     case 3: VSL_OCC(1, true); break;
@@ -889,7 +894,7 @@ int vsl_loss_forward_static(const vsl_loss_desc* d, float* losses, float* identi
   // forward only: the gradient planes would have to outlive the call in memory the caller cannot name
   vsl_loss_desc fd = *d;
   fd.flags |= VSL_FLAG_NO_GRAD;
-  const size_t need = make_layout(fd.B, fd.H, fd.W, desc_tile_h(&fd)).total;
+  const size_t need = make_layout(fd.B, fd.H, fd.W, desc_tile_h(&fd), desc_tile_w(&fd)).total;
   if (need > kStaticScratchBytes)
     return fail(VSL_ERR_WORKSPACE_TOO_SMALL,
                 "vsl_loss_forward_static: this shape needs " + std::to_string(need) + " bytes of scratch, the library holds " +
@@ -945,7 +950,7 @@ int vsl_identity_min(const vsl_loss_desc* d, float* identity_min, void* stream_)
     if (!d->source[s]) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL source image");
   KParams kp = base_params(d);
   kp.idmin = identity_min;
-  const Layout L = make_layout(d->B, d->H, d->W, kIdTH);
+  const Layout L = make_layout(d->B, d->H, d->W, kIdTH, kTW);
   launch_ident(kp, OutArgs{}, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0, dim3(swizzled_grid(L.blocks)), (hipStream_t)stream_);
   if (hipError_t e = hipGetLastError(); e != hipSuccess)
     return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));

@@ -33,20 +33,20 @@ void run_ident(const KParams& kp) {
 
 template <int S, bool AVG>
 void run_tiles(KParams kp) {
-  constexpr int kTH = fused_tile_h(S, AVG), kNT = tile_threads(kTH);
-  using F = Fused<kTW, kTH, kNT, S, AVG>;
-  using F1 = Fused<kTW, kTH, kNT, S, AVG, 1>;   // forward-only program
+  constexpr int kTH = fused_tile_h(S, AVG), kNT = tile_threads(kTH), kFW = fused_tile_w(S, AVG);
+  using F = Fused<kFW, kTH, kNT, S, AVG>;
+  using F1 = Fused<kFW, kTH, kNT, S, AVG, 1>;   // forward-only program
   if (kp.automask) run_ident<S, AVG>(kp);
   const bool fwd_only = kp.want_grad == 0;
-  const int tx = (kp.W + kTW - 1) / kTW, ty = (kp.H + kTH - 1) / kTH;
+  const int tx = (kp.W + kFW - 1) / kFW, ty = (kp.H + kTH - 1) / kTH;
   std::vector<float> lds(F::LDS_FLOATS > F1::LDS_FLOATS ? F::LDS_FLOATS : F1::LDS_FLOATS);
   std::vector<ThreadState<S>> st(kNT);
   const HeadView hv = head_view(kp);
   for (int b = 0; b < kp.B; ++b)
     for (int by = 0; by < ty; ++by)
       for (int bx = 0; bx < tx; ++bx) {
-        typename F::Block bk{b, bx * kTW, by * kTH};
-        typename F1::Block bk1{b, bx * kTW, by * kTH};
+        typename F::Block bk{b, bx * kFW, by * kTH};
+        typename F1::Block bk1{b, bx * kFW, by * kTH};
         const int lin = (b * ty + by) * tx + bx;
         // poison LDS so that reads of unwritten cells show up as NaNs in the results
         for (auto& v : lds) v = NAN;
@@ -82,6 +82,6 @@ extern "C" int vsl_emu_tiles(const KParams* kp, int avg) {
 }
 
 extern "C" int vsl_emu_part_stride() { return kPartStride; }
-extern "C" int vsl_emu_tile_w() { return kTW; }
+extern "C" int vsl_emu_tile_w(int S, int avg) { return fused_tile_w(S, avg != 0); }
 extern "C" int vsl_emu_tile_h(int S, int avg) { return fused_tile_h(S, avg != 0); }
 extern "C" int vsl_emu_kparams_size() { return (int)sizeof(KParams); }
