@@ -172,13 +172,6 @@ int vsl_smooth_bwd(const float* disp, const float* img, const float* g_loss, flo
 /* Message of the last error raised on the calling thread ("" if none). */
 const char* vsl_last_error_string(void);
 
-/* Diagnostic: q[i] = a[i] / b[i] through the shared-divisor division the fused kernel uses for its sampling
- * coordinates (device arrays of n floats); the tests compare it bit for bit with IEEE float32 division. */
-int vsl_debug_quot(const float* a, const float* b, float* q, long long n, void* stream);
-
-/* Diagnostic: workgroups of the fused kernel the runtime expects to fit on one CU for S sources. */
-int vsl_debug_fused_occupancy(int S, int avg_reprojection);
-
 /*
  * Several disparity heads over the SAME images, poses, intrinsics and flags in one call: what a
  * trainer that feeds a different disparity to every entry of opt.scales runs per step
@@ -230,12 +223,6 @@ int vsl_loss_forward_heads(const vsl_loss_desc* desc, const vsl_head* heads, int
 int vsl_loss_forward_static(const vsl_loss_desc* desc, float* losses, float* identity_selection, void* stream);
 
 int vsl_loss_backward_heads(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, void* stream);
-
-/* Diagnostic / benchmarking: runs vsl_loss_forward_heads `reps` times and returns in *avg_ms (host) the
- * average duration of the fused tile kernel alone, from HIP events recorded on `stream` directly around that
- * launch.  Synchronises the host; creates and destroys two events. */
-int vsl_debug_time_fused(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, int reps, float* avg_ms,
-                         void* stream);
 
 /*
  * Pose preparation in front of the loss: transformation_from_parameters (Python/layers.py:28-45, with

@@ -2,12 +2,14 @@
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvsloss.so")
+RESOURCES = os.path.join(HERE, "libvsloss.resources.txt")
 SOURCES = ["vsl_loss.hip", "vsl_layers.hip", "vsl_pose.hip", "vsl_metrics.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -28,13 +30,56 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # reference's float32 results (1.5e-5 instead of 1e-6 relative on the golden fixtures).
     # -fno-slp-vectorize: packed f32 math has no rate advantage on gfx950 and its operand pairing costs
     # register moves (measured 3 % slower with it).
-    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=on", "-fno-slp-vectorize", "-shared", "-fPIC",
+    cmd = [HIPCC, "-Rpass-analysis=kernel-resource-usage", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=on",
+           "-fno-slp-vectorize", "-shared", "-fPIC",
            "-I", os.path.join(HERE, "..", "include"), "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    table = kernel_resources(proc.stderr)
+    other, after_remark = [], False  # everything but the remarks and the source excerpts printed under them
+    for ln in proc.stderr.splitlines():
+        if "-Rpass-analysis=kernel-resource-usage" in ln:
+            after_remark = True
+        elif not (after_remark and re.match(r"\s*\d*\s*\|", ln)):
+            after_remark = False
+            other.append(ln)
+    if other:
+        print("\n".join(other), file=sys.stderr)
+    if proc.returncode != 0:
+        raise subprocess.CalledProcessError(proc.returncode, cmd)
+    with open(RESOURCES, "w") as f:
+        f.write("# kernel  VGPRs  SGPR-spills  VGPR-spills  scratch-bytes-per-lane  LDS-bytes\n")
+        for k in table:
+            f.write("%s %d %d %d %d %d\n" % (k["name"], k["vgprs"], k["sgpr_spill"], k["vgpr_spill"], k["scratch"], k["lds"]))
+    if verbose:
+        print(open(RESOURCES).read(), file=sys.stderr)
+    # A private array that the compiler cannot keep in registers lands in scratch memory and is written back to HBM
+    # by every wave (one such array of 16 B per lane doubled the tile kernel's HBM writes without changing a result):
+    # no kernel of this library may have any.
+    bad = [k["name"] for k in table if k["scratch"] or k["vgpr_spill"]]
+    if bad:
+        os.remove(OUT)
+        raise RuntimeError("kernels with scratch memory or vector-register spills: " + ", ".join(bad))
     return OUT
+
+
+def kernel_resources(remarks: str):
+    """The compiler's per-kernel resource remarks as a list of dicts."""
+    out, cur = [], None
+    keys = {"VGPRs": "vgprs", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
+            "ScratchSize [bytes/lane]": "scratch", "LDS Size [bytes/block]": "lds"}
+    for ln in remarks.splitlines():
+        m = re.search(r"remark:\s+(.*?):\s+(\S+) \[-Rpass-analysis", ln)
+        if not m:
+            continue
+        key, val = m.group(1).strip(), m.group(2)
+        if key == "Function Name":
+            cur = {"name": val, "vgprs": 0, "sgpr_spill": 0, "vgpr_spill": 0, "scratch": 0, "lds": 0}
+            out.append(cur)
+        elif cur is not None and key in keys:
+            cur[keys[key]] = int(val)
+    return out
 
 
 if __name__ == "__main__":

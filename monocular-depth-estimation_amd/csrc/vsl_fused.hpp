@@ -78,7 +78,10 @@ constexpr int fused_tile_h(int S, bool avg) { return (S <= 2 && !avg) ? VSL_TILE
 #ifndef VSL_TILE_W3
 #define VSL_TILE_W3 26
 #endif
-constexpr int fused_tile_w(int S, bool avg) { return (S == 3 && !avg) ? VSL_TILE_W3 : kTileW; }
+#ifndef VSL_TILE_W2
+#define VSL_TILE_W2 kTileW
+#endif
+constexpr int fused_tile_w(int S, bool avg) { return (S == 3 && !avg) ? VSL_TILE_W3 : ((S <= 2 && !avg) ? VSL_TILE_W2 : kTileW); }
 constexpr int tile_threads(int th) { return 16 * (th + 4); }
 constexpr float kC1 = 0.01f * 0.01f;
 constexpr float kC2 = 0.03f * 0.03f;
@@ -1449,12 +1452,18 @@ struct Fused {
     if constexpr (HALO == 2) {
       const int trow = tid / ROWP;
       if (trow >= 1 && trow <= TH) lds[tid - ROWP] = st.part[0];
-      if (trow < TH) {
+      // The first three stores pick value and slot with selects: as two branches storing st.part[4 + j] and
+      // st.part[1 + j], the compiler merges them into one store through a selected address of st.part, which
+      // moves the array to scratch memory (16 B per lane written to HBM by every tile).
+      const bool big = trow < TH;
 #pragma unroll
-        for (int i = 1; i < NBIG; ++i) lds[i * BIG_PITCH + tid] = st.part[3 + i];
-      } else {
+      for (int j = 0; j < 3; ++j) {
+        const float v = big ? st.part[4 + j] : st.part[1 + j];
+        lds[big ? (1 + j) * BIG_PITCH + tid : NBIG * BIG_PITCH + j * SMALL_PITCH + tid - BIG] = v;
+      }
+      if (big) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) lds[NBIG * BIG_PITCH + j * SMALL_PITCH + tid - BIG] = st.part[1 + j];
+        for (int i = 4; i < NBIG; ++i) lds[i * BIG_PITCH + tid] = st.part[3 + i];
       }
     } else {
 #pragma unroll

@@ -453,10 +453,28 @@ struct WarpSel {
   int C, local_group;
 };
 __device__ __forceinline__ WarpSel warp_select(const WarpArgs& a, const WarpPtrs& q, int g) {
-  WarpSel r{a.feats[0], q.p[0], a.C[0], g};
+  // every field is read before the first comparison and picked with selects of values: with the reads inside the
+  // conditional assignments the compiler merges them into one read through a selected address, which again is a
+  // run-time index into the argument structs
+  const float* f[kWarpMaxT];
+  float* o[kWarpMaxT];
+  int C[kWarpMaxT], start[kWarpMaxT];
 #pragma unroll
-  for (int t = 1; t < kWarpMaxT; ++t)
-    if (g >= a.gstart[t]) r = WarpSel{a.feats[t], q.p[t], a.C[t], g - a.gstart[t]};
+  for (int t = 0; t < kWarpMaxT; ++t) {
+    f[t] = a.feats[t];
+    o[t] = q.p[t];
+    C[t] = a.C[t];
+    start[t] = a.gstart[t];
+  }
+  WarpSel r{f[0], o[0], C[0], g};
+#pragma unroll
+  for (int t = 1; t < kWarpMaxT; ++t) {
+    const bool in = g >= start[t];
+    r.feats = in ? f[t] : r.feats;
+    r.ptr = in ? o[t] : r.ptr;
+    r.C = in ? C[t] : r.C;
+    r.local_group = in ? g - start[t] : r.local_group;
+  }
   return r;
 }
 

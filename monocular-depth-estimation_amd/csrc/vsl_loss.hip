@@ -10,11 +10,13 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 #include <string>
 
 #include "../../include/vsloss.h"
+#include "../../include/vsloss_debug.h"
 #include "vsl_fused.hpp"
 
 namespace vsl_err {
@@ -489,7 +491,10 @@ Layout make_layout(int B, int H, int W, int th, int tw) {
   return L;
 }
 
-int check_desc(const vsl_loss_desc* d) {
+// Limits every launch over the images of a descriptor relies on: 16-bit grid dimensions for the image index, 32-bit
+// element offsets into the image tensors, 28-bit offsets within a plane and 24-bit operands of the row-times-width
+// multiplies.
+int check_shape(const vsl_loss_desc* d) {
   if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
   if (d->B < 1 || d->H < 2 || d->W < 2) return fail(VSL_ERR_INVALID_ARGUMENT, "need B >= 1, H >= 2, W >= 2");
   if (d->B > 65535) return fail(VSL_ERR_INVALID_ARGUMENT, "B exceeds 65535");
@@ -498,8 +503,16 @@ int check_desc(const vsl_loss_desc* d) {
   if ((long long)d->H * d->W >= (1ll << 28) || d->H >= (1 << 24) || d->W >= (1 << 24))
     return fail(VSL_ERR_INVALID_ARGUMENT, "H*W must stay below 2^28 and H, W below 2^24");
   if (d->S < 1 || d->S > VSL_MAX_SOURCES) return fail(VSL_ERR_INVALID_ARGUMENT, "S must be 1..VSL_MAX_SOURCES");
+  return VSL_OK;
+}
+
+int check_desc(const vsl_loss_desc* d) {
+  if (int rc = check_shape(d)) return rc;
   if (!(d->min_depth > 0.0f) || !(d->max_depth > d->min_depth))
     return fail(VSL_ERR_INVALID_ARGUMENT, "need 0 < min_depth < max_depth");
+  // a zeroed or unset factor would silently return all-zero losses and gradients
+  if (!(d->inv_num_scales > 0.0f) || !std::isfinite(d->inv_num_scales))
+    return fail(VSL_ERR_INVALID_ARGUMENT, "inv_num_scales must be positive and finite (1 / num_scales)");
   if (!d->target || !d->K || !d->inv_K) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL input tensor");
   for (int s = 0; s < d->S; ++s)
     if (!d->source[s] || !d->T[s]) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL source image or pose");
@@ -942,9 +955,7 @@ int vsl_debug_time_fused(const vsl_loss_desc* d, const vsl_head* heads, int n_he
 }
 
 int vsl_identity_min(const vsl_loss_desc* d, float* identity_min, void* stream_) {
-  if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
-  if (d->B < 1 || d->B > 65535 || d->H < 2 || d->W < 2) return fail(VSL_ERR_INVALID_ARGUMENT, "need 1 <= B <= 65535, H >= 2, W >= 2");
-  if (d->S < 1 || d->S > VSL_MAX_SOURCES) return fail(VSL_ERR_INVALID_ARGUMENT, "S must be 1..VSL_MAX_SOURCES");
+  if (int rc = check_shape(d)) return rc;
   if (!d->target || !identity_min) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL tensor");
   for (int s = 0; s < d->S; ++s)
     if (!d->source[s]) return fail(VSL_ERR_INVALID_ARGUMENT, "NULL source image");

@@ -12,8 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     import mde_amd._abi as abi
-    header = open(os.path.join(ROOT, "include", "vsloss.h")).read()
-    declared = set(re.findall(r"\b(vsl_[a-z_]+)\s*\(", header))
+    declared = set()
+    for name in ("vsloss.h", "vsloss_debug.h"):
+        declared |= set(re.findall(r"\b(vsl_[a-z_]+)\s*\(", open(os.path.join(ROOT, "include", name)).read()))
+    boundary = open(os.path.join(ROOT, "include", "vsloss.h")).read()
+    assert "vsl_debug" not in boundary          # diagnostics live in their own header
     assert declared == set(abi.EXPORTS)
     for name in declared:
         assert hasattr(abi.lib, name), name
@@ -50,6 +53,45 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"2^28" in abi.lib.vsl_last_error_string()
     with pytest.raises(abi.VslError):
         abi.check(-1)
+
+
+def test_inv_num_scales_and_identity_min_limits_without_gpu():
+    """A zeroed inv_num_scales would silently zero every loss: rejected.  vsl_identity_min applies the same shape
+    limits as the loss entry points."""
+    import mde_amd._abi as abi
+    fake = 0x1000
+    err = lambda: abi.lib.vsl_last_error_string()
+    d = abi.LossDesc()
+    d.B, d.H, d.W, d.S, d.n_scales, d.min_depth, d.max_depth = 1, 8, 8, 1, 1, 0.1, 100.0
+    d.target = d.K = d.inv_K = d.disp = fake
+    d.source[0] = d.T[0] = fake
+    for bad in (0.0, -1.0, float("inf"), float("nan")):
+        d.inv_num_scales = bad
+        assert abi.lib.vsl_loss_forward(ctypes.byref(d), fake, 1 << 30, fake, None, None) == -1
+        assert b"inv_num_scales" in err()
+    d.inv_num_scales = 1.0
+    d.H, d.W = 2, 1 << 24
+    assert abi.lib.vsl_identity_min(ctypes.byref(d), fake, None) == -1 and b"2^24" in err()
+    d.H, d.W = 1 << 14, 1 << 14
+    assert abi.lib.vsl_identity_min(ctypes.byref(d), fake, None) == -1 and b"2^28" in err()
+    d.B, d.H, d.W = 1 << 12, 1 << 10, 1 << 10
+    assert abi.lib.vsl_identity_min(ctypes.byref(d), fake, None) == -1 and b"2^31" in err()
+    d.B, d.H, d.W, d.S = 1, 8, 8, 5
+    assert abi.lib.vsl_identity_min(ctypes.byref(d), fake, None) == -1
+    d.S = 1
+    assert abi.lib.vsl_identity_min(ctypes.byref(d), None, None) == -1 and b"NULL" in err()
+    assert abi.lib.vsl_identity_min(None, fake, None) == -1
+
+
+def test_no_kernel_uses_scratch_memory():
+    """The build records the compiler's per-kernel resources; a private array spilled to scratch memory is written
+    to HBM by every wave, so none is allowed (the build itself refuses such a library)."""
+    path = os.path.join(ROOT, "monocular-depth-estimation_amd", "libvsloss.resources.txt")
+    if not os.path.exists(path):
+        pytest.skip("library was not built by build.py in this tree")
+    rows = [ln.split() for ln in open(path) if not ln.startswith("#")]
+    assert len(rows) > 40
+    assert [r[0] for r in rows if int(r[3]) or int(r[4])] == []
 
 
 def test_head_validation_without_gpu():
