@@ -360,7 +360,7 @@ size_t vsl_depth_metrics_workspace_bytes(const vsl_depth_metrics_desc* desc);
 int vsl_depth_metrics(const vsl_depth_metrics_desc* desc, float* metrics, void* workspace, size_t workspace_bytes,
                       void* stream);
 
-/* Library version, e.g. 100 for 0.1.0. */
+/* Library version, e.g. 200 for 0.2.0 (the first with the 200-byte vsl_head). */
 int vsl_version(void);
 
 #ifdef __cplusplus

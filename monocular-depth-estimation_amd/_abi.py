@@ -21,6 +21,7 @@ LOSS_TOTAL, LOSS_PHOTO, LOSS_SMOOTH, LOSS_SCALE0 = 0, 1, 2, 3
 LOSS_SLOTS = 3 + MAX_SCALES
 STATIC_SCRATCH_BYTES = 4 << 20
 
+MIN_VERSION = 200
 EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", "vsl_identity_min",
            "vsl_loss_forward_heads", "vsl_loss_backward_heads", "vsl_loss_forward_static",
            "vsl_disp_to_depth_fwd", "vsl_disp_to_depth_bwd", "vsl_backproject_fwd", "vsl_backproject_bwd",
@@ -200,6 +201,8 @@ def _load():
     lib.vsl_last_error_string.argtypes = []
     lib.vsl_version.restype = ctypes.c_int
     lib.vsl_version.argtypes = []
+    if lib.vsl_version() < MIN_VERSION:  # an older build lays vsl_head out differently
+        raise ImportError("libvsloss.so is version %d, this binding needs >= %d: rebuild it" % (lib.vsl_version(), MIN_VERSION))
     return lib
 
 

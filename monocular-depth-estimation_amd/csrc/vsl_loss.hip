@@ -610,7 +610,7 @@ extern "C" {
 
 const char* vsl_last_error_string(void) { return vsl_err::g_err.c_str(); }
 
-int vsl_version(void) { return 100; }
+int vsl_version(void) { return 200; }  // 0.2.0: vsl_head grew to 200 bytes (optional outputs)
 
 size_t vsl_loss_workspace_bytes(const vsl_loss_desc* d) {
   if (!d || d->B < 1 || d->H < 1 || d->W < 1) return 0;

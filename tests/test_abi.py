@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(abi.EXPORTS)
     for name in declared:
         assert hasattr(abi.lib, name), name
-    assert abi.lib.vsl_version() >= 100
+    assert abi.lib.vsl_version() >= 200
 
 
 def test_descriptor_mirror_and_workspace_query():
