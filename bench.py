@@ -347,8 +347,9 @@ def main():
                          "frac_whole_call": alg_bytes / (head_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "copy_ceiling_GBs": ceiling,
                          "traffic_source": "committed rocprofv3 PMC passes (profiles/), not this run",
-                         "limiter": "not HBM: 4 waves per SIMD (LDS- and register-bound) x the latency of a wave's "
-                                    "instruction stream; VALU issue slots 58 % used, HBM 18 % of peak (profiles/)"},
+                         "limiter": "not HBM but the vector ALU: the executed instructions of the four resident waves, priced "
+                                    "at their measured issue cost, fill about 87 % of a SIMD's time (59 % at 2 cycles each); "
+                                    "HBM runs at 18 % of peak (profiles/r02_valu_budget.txt, r02_pmc_pipes.txt)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(data, B, H, W, fids)
