@@ -348,7 +348,7 @@ def main():
                          "copy_ceiling_GBs": ceiling,
                          "traffic_source": "committed rocprofv3 PMC passes (profiles/), not this run",
                          "limiter": "not HBM but the vector ALU: the executed instructions of the four resident waves, priced "
-                                    "at their measured issue cost, fill about 87 % of a SIMD's time (59 % at 2 cycles each); "
+                                    "at their measured issue cost, fill 59 % (2 cycles each) to 87 % (class penalties) of a SIMD's time; "
                                     "HBM runs at 18 % of peak (profiles/r02_valu_budget.txt, r02_pmc_pipes.txt)"},
         }
         if not args.no_cpu_baseline and world == 1:
