@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--tiny", action="store_true", help="three-convolution stand-in networks instead of ResNet-18")
     ap.add_argument("--channels-last", action="store_true", help="run the networks in channels_last memory format")
+    ap.add_argument("--amp", action="store_true", help="networks under torch.autocast(bfloat16); the loss stays float32")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo")
     ap.add_argument("--force-ddp", action="store_true", help="wrap the networks in DistributedDataParallel even with one rank")
     args = ap.parse_args()
@@ -123,7 +124,8 @@ def main():
     if ddp:
         net = nn.parallel.DistributedDataParallel(net, device_ids=[dev.index])
     # every decoder scale is a disparity head of the loss (upsampled to full resolution, Trainer.py:431)
-    step = TrainStep(opt, net, torch.optim.Adam(params, opt.learning_rate), per_scale=not args.tiny)
+    step = TrainStep(opt, net, torch.optim.Adam(params, opt.learning_rate), per_scale=not args.tiny,
+                     autocast_dtype=torch.bfloat16 if args.amp else None)
 
     data = synth.make_batch(args.batch, args.height, args.width, opt.frame_ids, seed=100 + rank)
     inputs = {"K": data["K"].to(dev), "inv_K": data["inv_K"].to(dev)}
@@ -173,7 +175,7 @@ def main():
         ms = 1e3 * t.item() / args.steps
         print(json.dumps({"what": "synthetic end-to-end training step, %s networks, %d params" % (
                               "stand-in" if args.tiny else "ResNet-18 encoder + depth decoder + pose decoder", n_params),
-                          "n_gpus": world, "ddp": ddp, "steps": args.steps, "batch_per_gpu": args.batch,
+                          "n_gpus": world, "ddp": ddp, "network_dtype": "bf16 autocast" if args.amp else "f32", "steps": args.steps, "batch_per_gpu": args.batch,
                           "frames_per_s": world * args.batch * args.steps / t.item(), "ms_per_step": ms,
                           "loss_ms_per_step": loss_ms, "loss_share_of_step": loss_ms / ms,
                           "first_loss": first, "last_loss": last}))

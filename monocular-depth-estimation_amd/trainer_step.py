@@ -86,31 +86,47 @@ class NetworkPass(torch.nn.Module):
         return self.models["pose"](pose_inputs)
 
 
+def _to_float32(v):
+    if isinstance(v, dict):
+        return {k: _to_float32(x) for k, x in v.items()}
+    return v.float() if torch.is_tensor(v) and v.is_floating_point() else v
+
+
 class TrainStep:
     def __init__(self, opt, models: Union[Dict[str, torch.nn.Module], torch.nn.Module],
                  optimizer: Optional[torch.optim.Optimizer] = None, num_scales: int = 1, materialise: bool = False,
-                 use_pose_net: bool = True, per_scale: bool = False):
+                 use_pose_net: bool = True, per_scale: bool = False, autocast_dtype: Optional[torch.dtype] = None):
         """``models``: the dict of networks, or a module with NetworkPass's forward (e.g. a NetworkPass wrapped in
         DistributedDataParallel).  ``per_scale``: feed ("disp", s) of every scale to the loss
-        (compute_losses_per_scale) instead of the reference's ("disp", 0) everywhere."""
+        (compute_losses_per_scale) instead of the reference's ("disp", 0) everywhere.  ``autocast_dtype``: run the
+        networks under torch.autocast with that type (e.g. torch.bfloat16); their outputs are cast back to float32, the
+        loss always computes in float32."""
         self.opt = opt
         self.net = NetworkPass(opt, models, use_pose_net) if isinstance(models, dict) else models
         self.optimizer = optimizer
         self.materialise = materialise
         self.per_scale = per_scale
+        self.autocast_dtype = autocast_dtype
         self.loss = ViewSynthesisLoss(opt, num_scales=num_scales)
 
     # ------------------------------------------------------------------ Trainer.py:328-358
     def process_batch(self, inputs: Dict, noise: Optional[torch.Tensor] = None) -> Tuple[Dict, Dict]:
-        outputs = dict(self.net({f: inputs[("image_aug", f)] for f in self.opt.frame_ids}))
+        images = {f: inputs[("image_aug", f)] for f in self.opt.frame_ids}
+        if self.autocast_dtype is None:
+            outputs = dict(self.net(images))
+        else:
+            with torch.autocast(images[self.opt.frame_ids[0]].device.type, dtype=self.autocast_dtype):
+                outputs = dict(self.net(images))
+            outputs = {k: _to_float32(v) for k, v in outputs.items()}
         if "axisangle" in outputs:
             outputs.update(self.loss.pose_outputs(outputs.pop("axisangle"), outputs.pop("translation")))
-        if self.materialise:
-            self.loss.generate_images_pred(inputs, outputs)
         if self.per_scale:
+            if self.materialise:
+                self.loss.generate_images_pred(inputs, outputs)   # per-module kernels: the heads call has one pose set, many disparities
             losses = self.loss.compute_losses_per_scale(inputs, outputs, noise)
         else:
-            losses = self.loss.compute_losses(inputs, outputs, noise)
+            # ("depth",0), ("sample",f), ("color",f) come out of the loss launch itself when asked for
+            losses = self.loss.compute_losses(inputs, outputs, noise, materialise=self.materialise)
         return outputs, losses
 
     # ------------------------------------------------------------------ Trainer.py:217-243
