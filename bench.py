@@ -271,14 +271,19 @@ def main():
         torch.cuda.synchronize(dev)
 
     # Order of the measurements: the call-level breakdown and the copy ceiling first, then the W warm-up and K timed
-    # steps, then the dominant kernel alone.  The first tenth of a second of GPU work in a process runs at lower
+    # steps, then the dominant kernel alone.  The first few tenths of a second of GPU work in a process run at lower
     # clocks; a training run spends all but its first steps past that, so the timed steps are not placed there.
     import mde_amd._abi as abi
     d0 = step.descs[0]
     reps = 100
     n_launch_heads = step.n_heads if step.merged else 1
-    for _ in range(10):
-        step(stream, stream_obj)
+    # untimed: half a second of steps, by which time the clocks of a cold process have settled (launch durations
+    # under rocprofv3 fall from 277 to 221 us over the first 200 launches, profiles/r02_fused_trace_percentiles.txt)
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 0.5:
+        for _ in range(50):
+            step(stream, stream_obj)
+        torch.cuda.synchronize(dev)
     # whole forward and whole backward call (all their kernels), for the breakdown
     k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)

@@ -18,6 +18,7 @@ timeout -k 10 420 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout
  && timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pw -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 \
  && python tools/pmc_summary.py --traffic 640x192_b12_S2_heads4 $OUT/pmc_traffic.json $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.log 2>&1 \
  && find $OUT/ktrace -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \; \
+ && python tools/trace_percentiles.py $OUT/ktrace vsl_fused_kernel > $OUT/fused_trace_percentiles.txt \
  && find $OUT/ktrace -name '*kernel_trace.csv' -delete \
  && find $OUT/pmc_fetch $OUT/pmc_write -name '*counter_collection.csv' -size +8M -delete ; \
  echo "exit chain: $?"; ls -la $OUT
