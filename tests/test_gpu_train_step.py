@@ -179,6 +179,14 @@ def test_train_step_under_ddp_rccl_world_size_one():
             step = TrainStep(opt, net, torch.optim.Adam(params, 1e-3))
             runs.append([step.train_step(inputs, data["noise"].to(DEV))[1]["loss"].item() for _ in range(3)])
             torch.cuda.synchronize()
+            if wrap:
+                # the collectives bench.py --gpus N and the sharded driver issue, on the same RCCL group
+                import mde_amd.dist as D
+                D.barrier()
+                assert D.max_over_ranks(1.25, torch.device(DEV)) == 1.25
+                g = [torch.full((5,), 3.0, device=DEV), torch.full((2, 3), -1.0, device=DEV)]
+                D.all_reduce_mean_(g, bucket_bytes=16)
+                assert float(g[0].sum()) == 15.0 and float(g[1].sum()) == -6.0
         finally:
             if wrap:
                 td.destroy_process_group()
