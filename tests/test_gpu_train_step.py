@@ -192,3 +192,27 @@ def test_train_step_under_ddp_rccl_world_size_one():
                 td.destroy_process_group()
     assert all(np.isfinite(runs[1])) and runs[1][-1] < runs[1][0]
     assert runs[0][0] == runs[1][0] and np.allclose(runs[0], runs[1], rtol=1e-6, atol=0)
+
+
+def test_train_step_with_autocast_networks_and_materialised_outputs():
+    """Networks under bfloat16 autocast, loss in float32; with materialise the loss launch itself leaves
+    ("depth",0), ("sample",f), ("color",f) in `outputs` (Python/Trainer.py:436,464,467), equal to the per-module chain."""
+    from mde_amd.trainer_step import TrainStep
+    opt, models, params, _, data, inputs = _setup("all")
+    step = TrainStep(opt, models, torch.optim.Adam(params, 1e-3), materialise=True, autocast_dtype=torch.bfloat16)
+    noise = data["noise"].to(DEV)
+    outputs, losses = step.process_batch(inputs, noise)
+    assert outputs[("disp", 0)].dtype == torch.float32 and outputs[("cam_T_cam", -1)].dtype == torch.float32
+    assert torch.isfinite(losses["loss"]).all()
+    losses["loss"].backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    ref = dict(outputs)
+    for k in [("depth", 0)] + [(n, f) for n in ("sample", "color") for f in (-1, 1)]:
+        ref.pop(k)
+    step.loss.generate_images_pred(inputs, ref)                      # per-module kernels on the same network outputs
+    assert torch.equal(outputs[("depth", 0)], ref[("depth", 0)])
+    for f in (-1, 1):
+        assert torch.equal(outputs[("sample", f)], ref[("sample", f)])
+        assert torch.equal(outputs[("color", f)], ref[("color", f)].float())
+    values = [step.train_step(inputs, noise)[1]["loss"].item() for _ in range(6)]
+    assert all(np.isfinite(values)) and values[-1] < values[0]
