@@ -9,6 +9,8 @@
 #define R8(x) R4(x) R4(x)
 #define R16(x) R8(x) R8(x)
 #define R32(x) R16(x) R16(x)
+#define R512(x) R32(R16(x))
+#define R1024(x) R32(R32(x))
 
 #define OPERANDS                                                                                          \
   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(d0), "+v"(d1)                                              \
@@ -105,6 +107,11 @@ __global__ void __launch_bounds__(1024) k(float* out, const float* in, int iters
   PATTERN(73, 32, R8, "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_fmac_f32 %1, %6, %7\n v_fmac_f32 %2, %6, %7\n v_fmac_f32 %3, %6, %7\n")
   PATTERN(74, 32, R16, "v_med3_f32 %0, %0, %6, %7\n v_fmac_f32 %1, %6, %7\n")
   PATTERN(75, 32, R16, "v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n")
+  // long straight-line bodies (2048 instructions, the size of the tile kernels): does instruction fetch keep up?
+  PATTERN(76, 2048, R1024, "v_fmac_f32 %0, %6, %7\n v_fmac_f32 %1, %6, %7\n")
+  PATTERN(77, 2048, R1024, "v_fma_f32 %0, %0, %6, %7\n v_fma_f32 %1, %1, %6, %7\n")
+  PATTERN(78, 2048, R1024, "v_fmaak_f32 %0, %0, %6, 0x3f800347\n v_fmaak_f32 %1, %1, %7, 0x3f800347\n")
+  PATTERN(79, 2048, R512, "v_fma_f32 %0, %0, %6, %7\n v_fmac_f32 %1, %6, %7\n v_fma_f32 %2, %2, %6, %7\n v_fmac_f32 %3, %6, %7\n")
   if (threadIdx.x == 0 && blockIdx.x == 0) *n_out = n_valu;
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (float)d0 + (float)d1;
 }
@@ -127,7 +134,8 @@ static const char* kNames[] = {
     "sub_u32 A / B", "fmaak literal A / B", "mul sgpr A / fmac B / fmac C", "cvt A / fmac B", "mad_u32_u24 A / fmac B",
     "mul_lo_u32 A / fmac B C D", "fma_f64 A / fmac B C D", "rcp A / 7 fmac", "mov_dpp A / fmac B C D", "cmp vcc A / fmac B",
     "s_mov / fmac A B C (3 valu of 4)", "s_waitcnt / fmac A B C (3 valu)", "fma_f64 A / add_f64 B", "cvt_f64_f32 A / fmac B",
-    "add_f32_dpp A / fmac B C D", "med3 A / fmac B", "mul sgpr A / mul sgpr B (same sgpr)"};
+    "add_f32_dpp A / fmac B C D", "med3 A / fmac B", "mul sgpr A / mul sgpr B (same sgpr)",
+    "2048 x fmac (4-byte encoding)", "2048 x fma e64 (8-byte encoding)", "2048 x fmaak (8 bytes with literal)", "2048 x fma e64 / fmac mixed (6 bytes avg)"};
 
 int main() {
   float* d;
@@ -148,7 +156,7 @@ int main() {
       hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, d, zin, 100, mode, n);
       (void)hipDeviceSynchronize();
       (void)hipEventRecord(e0);
-      hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, d, zin, iters, mode, n);
+      hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, d, zin, mode >= 76 ? iters / 64 : iters, mode, n);
       (void)hipEventRecord(e1);
       (void)hipEventSynchronize(e1);
       float ms;
@@ -156,7 +164,7 @@ int main() {
       int n_valu = 0;
       (void)hipMemcpy(&n_valu, n, 4, hipMemcpyDeviceToHost);
       const double waves = threads / 256.0;
-      const double ns = ms * 1e6 / ((double)iters * n_valu * waves);
+      const double ns = ms * 1e6 / ((double)(mode >= 76 ? iters / 64 : iters) * n_valu * waves);
       printf("%2d %-40s waves/SIMD %.0f: %7.3f ms  %5.2f ns per vector instruction per SIMD\n", mode, kNames[mode], waves, ms, ns);
     }
   }
