@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void vsl_grad_kernel(const GradParams gp) {
         gh.grad_disp[off + i] = ap * gh.gphoto[off + i] + (c1 * gh.gedge[off + i] - c2);
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < gp.S * 16) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < gp.S * 16) {
     const int s = threadIdx.x / 16, e = threadIdx.x % 16;
     if (gh.grad_T[s]) gh.grad_T[s][b * 16 + e] = ap * gh.gT[((size_t)s * gp.B + b) * 16 + e];
   }
