@@ -373,9 +373,11 @@ VSL_DEV TileTaps tile_taps(float g, int n) {
   return tp;
 }
 
-// What phase 3 needs from phase 1 for one (pixel, source): where the four bilinear taps are and
-// their fractions.  Three registers instead of the six tap derivatives; phase 3 fetches the taps
-// again (they are cache hits) and rebuilds the derivatives.
+// What phase 3 needs from phase 1 for one (pixel, source).  With up to two sources the six tap derivatives
+// d warped_c / d ix, d iy themselves stay in registers (ThreadState::dp, Fused::CARRY).  With more sources there
+// is no room for them: three registers say where the four bilinear taps are and what their fractions are, and
+// phase 3 fetches the taps again (cache hits, but 24 more gathers per thread through the vector L1, which is the
+// busiest unit of the kernel: without them the two-source kernel is 10 % faster) and rebuilds the derivatives.
 struct Chain {
   float tx, ty;  // bilinear fractions; tx is relative to the texel pair below (1 when x0 = W-1)
   int packed;    // bits 0..27 offset of texel (y0, min(x0, W-2)) in the image plane: the 8 bytes there hold both
@@ -393,7 +395,9 @@ struct Mats {
 template <int S>
 struct ThreadState {
   Mats<S> m;
-  Chain ch[2][S];
+  Chain ch[2][S];            // programs that fetch the taps again in phase 3
+  float dp[2][S][3][2];      // programs that carry them: d warped_c / d ix, d iy of (pixel, source, channel), before the clip masks
+  unsigned live;             // with dp: bit 2 (k S + s) = d/dx passes (0 < ix < W-1), bit 2 (k S + s) + 1 = d/dy passes
   float photo;                  // sum of the selected photometric error over this thread's interior pixels
   float part[num_partials(S)];  // filled at the end of phase 3
 };
@@ -682,6 +686,10 @@ struct Fused {
   static constexpr int ROWP = 16;
   static constexpr int NSET = AVG ? S : 1;
   static constexpr int NPART = num_partials(S);
+  // The full program keeps the tap derivatives of phase 1 in registers for phase 3 where the register budget of its
+  // workgroups per CU allows (two sources: 110 / 122 of 128 registers; one source with the mean over sources sits
+  // at the 96 of five workgroups per CU already); the others fetch the taps again.
+  static constexpr bool CARRY = HALO == 2 && (S == 2 || (S == 1 && !AVG));
   static_assert(R2W / 2 <= ROWP && ROWP * R2H <= NT, "one R2 pair per thread, at most ROWP pairs per row");
   static_assert(P2 % 2 == 0 && P1 % 2 == 0, "planes must keep 8-byte alignment");
 
@@ -768,9 +776,18 @@ struct Fused {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int s = 0; s < S; ++s) st.ch[k][s] = Chain{0.0f, 0.0f, 0};
+        for (int s = 0; s < S; ++s) {
+          if constexpr (CARRY) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) st.dp[k][s][c][0] = st.dp[k][s][c][1] = 0.0f;
+          } else {
+            st.ch[k][s] = Chain{0.0f, 0.0f, 0};
+          }
+        }
+      if constexpr (CARRY) st.live = 0u;
       return;
     }
+    if constexpr (CARRY) st.live = 0u;
     // Full program: thread row t warps R2 row t + 2 (wrapping round), so that thread rows 0..TH-1 -- whole waves --
     // hold the tap records of the interior rows, which the same threads differentiate in phase 3, and the halo
     // rows fall to the last wave, which phase 3 gives the smoothness term instead.
@@ -845,12 +862,23 @@ struct Fused {
           const float wv = a.lo * w00 + a.hi * w01 + b.lo * w10 + b.hi * w11;
           lds[OFF_WRP + (s * 3 + c) * P2 + p2] = wv;
           if constexpr (OUT) emit_color(kp, hv, bk, ry, rx0 + k, pix, s, c, wv);
+          if constexpr (CARRY) {
+            // by every thread, also those of the halo rows that never use them: a branch here would end the basic
+            // block, and the compiler then waits for each pair of gathers before it issues the next (measured +5 %)
+            const float v00 = a.lo, v01 = a.hi, v10 = b.lo, v11 = b.hi;
+            st.dp[k][s][c][0] = (1.0f - ty.t) * (v01 - v00) + ty.t * (v11 - v10);
+            st.dp[k][s][c][1] = (1.0f - txe) * (v10 - v00) + txe * (v11 - v01);
+          }
         }
-        Chain& ch = st.ch[k][s];
-        ch.tx = txe;
-        ch.ty = ty.t;
-        ch.packed = (int)(o0 | ((unsigned)ys << 29) | ((unsigned)tx.live << 30) |
-                          ((unsigned)ty.live << 31));
+        if constexpr (CARRY) {
+          st.live |= ((unsigned)tx.live | ((unsigned)ty.live << 1)) << (2 * (k * S + s));
+        } else {
+          Chain& ch = st.ch[k][s];
+          ch.tx = txe;
+          ch.ty = ty.t;
+          ch.packed = (int)(o0 | ((unsigned)ys << 29) | ((unsigned)tx.live << 30) |
+                            ((unsigned)ty.live << 31));
+        }
       }
     }
   }
@@ -1233,39 +1261,54 @@ struct Fused {
       }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        // fetch the bilinear taps of both pixels again (cache hits)
-        float tv[2][3][4];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const unsigned pk = (unsigned)chn[k][s].packed;
-          const unsigned o0 = pk & 0x0FFFFFFFu;
-          const unsigned o1 = o0 + (((pk >> 29) & 1u) ? (unsigned)W : 0u);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float* pc = src_image(kp, s) + ((size_t)bk.b * 3 + c) * HW;
-            const TexelPair a = load_texel_pair_at(pc, o0 << 2), b = load_texel_pair_at(pc, o1 << 2);
-            tv[k][c][0] = a.lo;
-            tv[k][c][1] = a.hi;
-            tv[k][c][2] = b.lo;
-            tv[k][c][3] = b.hi;
-          }
-        }
         // tap derivatives d warped_c / d ix, d iy (zero outside the clip range) and the chain to (ix, iy)
         float gix[2] = {0.0f, 0.0f}, giy[2] = {0.0f, 0.0f};
+        if constexpr (CARRY) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const Chain ch = chn[k][s];
-          const float lx = (float)((ch.packed >> 30) & 1), ly = (float)((ch.packed >> 31) & 1);
+          for (int k = 0; k < 2; ++k) {
+            const unsigned bits = st.live >> (2 * (k * S + s));
+            const float lx = (float)(bits & 1u), ly = (float)((bits >> 1) & 1u);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float v00 = tv[k][c][0], v01 = tv[k][c][1], v10 = tv[k][c][2], v11 = tv[k][c][3];
-            const float dpx = (1.0f - ch.ty) * (v01 - v00) + ch.ty * (v11 - v10);
-            const float dpy = (1.0f - ch.tx) * (v10 - v00) + ch.tx * (v11 - v01);
-            gix[k] = fmaf(g[s][k][c], dpx, gix[k]);
-            giy[k] = fmaf(g[s][k][c], dpy, giy[k]);
+            for (int c = 0; c < 3; ++c) {
+              gix[k] = fmaf(g[s][k][c], st.dp[k][s][c][0], gix[k]);
+              giy[k] = fmaf(g[s][k][c], st.dp[k][s][c][1], giy[k]);
+            }
+            gix[k] *= lx;
+            giy[k] *= ly;
           }
-          gix[k] *= lx;
-          giy[k] *= ly;
+        } else {
+          // fetch the bilinear taps of both pixels again (cache hits)
+          float tv[2][3][4];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const unsigned pk = (unsigned)chn[k][s].packed;
+            const unsigned o0 = pk & 0x0FFFFFFFu;
+            const unsigned o1 = o0 + (((pk >> 29) & 1u) ? (unsigned)W : 0u);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float* pc = src_image(kp, s) + ((size_t)bk.b * 3 + c) * HW;
+              const TexelPair a = load_texel_pair_at(pc, o0 << 2), b = load_texel_pair_at(pc, o1 << 2);
+              tv[k][c][0] = a.lo;
+              tv[k][c][1] = a.hi;
+              tv[k][c][2] = b.lo;
+              tv[k][c][3] = b.hi;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const Chain ch = chn[k][s];
+            const float lx = (float)((ch.packed >> 30) & 1), ly = (float)((ch.packed >> 31) & 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float v00 = tv[k][c][0], v01 = tv[k][c][1], v10 = tv[k][c][2], v11 = tv[k][c][3];
+              const float dpx = (1.0f - ch.ty) * (v01 - v00) + ch.ty * (v11 - v10);
+              const float dpy = (1.0f - ch.tx) * (v10 - v00) + ch.tx * (v11 - v01);
+              gix[k] = fmaf(g[s][k][c], dpx, gix[k]);
+              giy[k] = fmaf(g[s][k][c], dpy, giy[k]);
+            }
+            gix[k] *= lx;
+            giy[k] *= ly;
+          }
         }
         const float* P = st.m.P[s];
 #pragma unroll
