@@ -75,26 +75,39 @@ size_t g_stamp_bytes = 0;
 // (x fastest, then y, then image): horizontally and vertically adjacent tiles, which share 128-byte lines
 // of the images (a 28-pixel tile row is 112 bytes), then meet in the same L2 at about the same time.
 // Returns the tile's linear index (x fastest), or -1 for the padding workgroups past the last tile.
-template <int TH, int TW>
-__device__ __forceinline__ int swizzled_tile(const KParams& kp, int n_heads, int& head, int& b, int& x0, int& y0) {
-  const int tiles_x = (kp.W + TW - 1) / TW, tiles_y = (kp.H + TH - 1) / TH;
-  const int per_image = tiles_x * tiles_y;
-  const int per_head = per_image * kp.B;
-  const int chunk = (int)(gridDim.x >> 3);
+// The three divisors of that mapping, prepared on the host with floor(2^32 / d) each: a uniform integer division
+// costs the compiler about 35 vector and scalar instructions per wave, the multiply-high form six scalar ones.
+struct TileDiv {
+  unsigned tiles_x, per_image, per_head;  // tiles per tile row, per image, per head
+  unsigned m_x, m_image, m_head;          // min(floor(2^32 / d), 2^32 - 1)
+};
+// t / d and t % d for any t < 2^32: the multiply-high quotient is floor(t / d) or one less
+__device__ __forceinline__ unsigned div_prepared(unsigned t, unsigned d, unsigned m, unsigned& rem) {
+  unsigned q = __umulhi(t, m);
+  unsigned r = t - q * d;
+  if (r >= d) {
+    ++q;
+    r -= d;
+  }
+  rem = r;
+  return q;
+}
+__device__ __forceinline__ int swizzled_tile(const TileDiv& td, int tile_w, int tile_h, int n_heads, int& head, int& b, int& x0,
+                                             int& y0) {
+  const unsigned chunk = gridDim.x >> 3;
 #ifdef VSL_NO_SWIZZLE
-  int t = (int)blockIdx.x;
+  unsigned t = blockIdx.x;
 #else
-  int t = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+  unsigned t = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
 #endif
-  if (t >= per_head * n_heads) return -1;
-  head = t / per_head;
-  t -= head * per_head;
-  b = t / per_image;
-  const int r = t - b * per_image;
-  const int ty = r / tiles_x;
-  x0 = (r - ty * tiles_x) * TW;
-  y0 = ty * TH;
-  return t;
+  if (t >= td.per_head * (unsigned)n_heads) return -1;
+  unsigned in_head, in_image, tx;
+  head = (int)div_prepared(t, td.per_head, td.m_head, in_head);
+  b = (int)div_prepared(in_head, td.per_image, td.m_image, in_image);
+  const unsigned ty = div_prepared(in_image, td.tiles_x, td.m_x, tx);
+  x0 = (int)tx * tile_w;
+  y0 = (int)ty * tile_h;
+  return (int)in_head;
 }
 
 // Per-head part of the fused kernel's arguments: several disparity heads over the same images and poses run
@@ -110,6 +123,7 @@ struct HeadArgs {
   float cst_ssim[VSL_MAX_HEADS], cst_l1[VSL_MAX_HEADS];
   int want_grad[VSL_MAX_HEADS];
   int index[VSL_MAX_HEADS];  // the head's position in the caller's table (a launch may cover a subset of the heads)
+  TileDiv td;
 };
 
 template <int S, bool AVG, bool OUT>
@@ -122,7 +136,7 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   const int tid = threadIdx.x;
   typename F::Block bk;
   int head = 0;
-  const int block_linear = swizzled_tile<TH, TW>(kp_in, ha.n_heads, head, bk.b, bk.x0, bk.y0);
+  const int block_linear = swizzled_tile(ha.td, TW, TH, ha.n_heads, head, bk.b, bk.x0, bk.y0);
   if (block_linear < 0) return;
   const KParams& kp = kp_in;
   // the head's pointers and constants (a patched copy of the argument struct would end up in scratch memory)
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG))) void vsl_forwar
   const int tid = threadIdx.x;
   typename F::Block bk;
   int head = 0;
-  const int block_linear = swizzled_tile<TH, TW>(kp_in, ha.n_heads, head, bk.b, bk.x0, bk.y0);
+  const int block_linear = swizzled_tile(ha.td, TW, TH, ha.n_heads, head, bk.b, bk.x0, bk.y0);
   if (block_linear < 0) return;
   const KParams& kp = kp_in;
   const HeadView hv{ha.disp[head],     ha.gphoto[head],  ha.gedge[head],    ha.ident_sel[head],
@@ -208,6 +222,7 @@ __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG))) void vsl_forwar
 struct OutArgs {
   int n_heads;
   float* ptr[VSL_MAX_HEADS][kOutPtrs];
+  TileDiv td;  // of the identity launch's own tiling
 };
 __device__ __forceinline__ void store_out_table(const KParams& kp, const OutArgs& oa, int tid, int nt) {
   if (!kp.out_table) return;
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(kIdNT) void vsl_ident_kernel(const KParams kp, cons
   if (blockIdx.x == 0) store_out_table(kp, oa, threadIdx.x, kIdNT);
   if (kp.prep && blockIdx.x == 0)
     for (int i = threadIdx.x; i < kp.B * kPrepStride; i += kIdNT) kp.prep[i] = prep_entry(kp, i / kPrepStride, i % kPrepStride);
-  if (swizzled_tile<kIdTH, kTW>(kp, 1, head, bk.b, bk.x0, bk.y0) < 0) return;
+  if (swizzled_tile(oa.td, kTW, kIdTH, 1, head, bk.b, bk.x0, bk.y0) < 0) return;
   I::load(kp, bk, threadIdx.x, lds);
   __syncthreads();
   I::compute(kp, bk, threadIdx.x, lds);
@@ -447,6 +462,10 @@ void* static_scratch_ptr() {
 // --------------------------------------------------------------------------
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 inline unsigned swizzled_grid(int tiles) { return 8u * (unsigned)((tiles + 7) / 8); }  // see swizzled_tile()
+inline unsigned div_multiplier(unsigned d) {
+  const unsigned long long m = (1ull << 32) / d;
+  return m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)m;
+}
 
 struct Layout {
   int tiles_x, tiles_y, tiles_per_image, blocks;
@@ -489,6 +508,17 @@ Layout make_layout(int B, int H, int W, int th, int tw) {
   o += align256((size_t)VSL_MAX_HEADS * kOutPtrs * sizeof(float*));
   L.total = o;
   return L;
+}
+
+TileDiv make_tile_div(const Layout& L) {
+  TileDiv td;
+  td.tiles_x = (unsigned)L.tiles_x;
+  td.per_image = (unsigned)L.tiles_per_image;
+  td.per_head = (unsigned)L.blocks;
+  td.m_x = div_multiplier(td.tiles_x);
+  td.m_image = div_multiplier(td.per_image);
+  td.m_head = div_multiplier(td.per_head);
+  return td;
 }
 
 // Limits every launch over the images of a descriptor relies on: 16-bit grid dimensions for the image index, 32-bit
@@ -735,7 +765,9 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
   kp.out_table = any_out ? (float**)((char*)heads[0].workspace + L.off_outs) : nullptr;
   if (automask && !d->identity_min) {  // computed once into the first head's workspace and read by every head
     kp.idmin = (float*)((char*)heads[0].workspace + L.off_idmin);
-    launch_ident(kp, oa, avg, dim3(swizzled_grid(make_layout(d->B, d->H, d->W, kIdTH, kTW).blocks)), stream);
+    const Layout LI = make_layout(d->B, d->H, d->W, kIdTH, kTW);
+    oa.td = make_tile_div(LI);
+    launch_ident(kp, oa, avg, dim3(swizzled_grid(LI.blocks)), stream);
   } else {
     if (automask) kp.idmin = const_cast<float*>(d->identity_min);
     hipLaunchKernelGGL(vsl_prep_kernel, dim3((d->B * kPrepStride + 255) / 256 > 64 ? 64 : (d->B * kPrepStride + 255) / 256), dim3(256), 0,
@@ -747,6 +779,7 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
   // through the forward-only one (halo 1, no coefficient planes: about half the time per head): two grids when
   // a call has both kinds.
   HeadArgs hg{}, hf{};
+  hg.td = hf.td = make_tile_div(L);
   auto take = [&](HeadArgs& dst, int h) {
     const int i = dst.n_heads++;
     dst.disp[i] = ha.disp[h];
@@ -962,7 +995,9 @@ int vsl_identity_min(const vsl_loss_desc* d, float* identity_min, void* stream_)
   KParams kp = base_params(d);
   kp.idmin = identity_min;
   const Layout L = make_layout(d->B, d->H, d->W, kIdTH, kTW);
-  launch_ident(kp, OutArgs{}, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0, dim3(swizzled_grid(L.blocks)), (hipStream_t)stream_);
+  OutArgs oa{};
+  oa.td = make_tile_div(L);
+  launch_ident(kp, oa, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0, dim3(swizzled_grid(L.blocks)), (hipStream_t)stream_);
   if (hipError_t e = hipGetLastError(); e != hipSuccess)
     return fail(VSL_ERR_LAUNCH_FAILED, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return VSL_OK;
