@@ -463,23 +463,26 @@ VSL_DEV SsimOut ssim_formula(float cx, float cy, float sx, float sxx, float sxy,
   constexpr float i9 = 1.0f / 9.0f;
   const float mxp = sx * i9;
   const float mux = cx + mxp, muy = cy + myp;
-  const float vx = fmaf(sxx, i9, -mxp * mxp);
-  const float cxy = fmaf(sxy, i9, -mxp * myp);
+  // variance and covariance as (sum of products - sum * mean) / 9, the division folded into the next step:
+  // d2 = var_x + (var_y + C2), n2 = 2 cov + C2
+  const float d2 = fmaf(fmaf(-sx, mxp, sxx), i9, vyc);
+  const float n2 = fmaf(fmaf(-sx, myp, sxy), 2.0f * i9, kC2);
   const float n1 = fmaf(2.0f * mux, muy, kC1);
-  const float n2 = fmaf(2.0f, cxy, kC2);
   const float d1 = fmaf(mux, mux, fmaf(muy, muy, kC1));
-  const float d2 = vx + vyc;
   const float inv = fast_rcp(d1 * d2);
   const float val = fmaf(-0.5f * n1, n2 * inv, 0.5f);
   SsimOut o;
   o.f = fminf(fmaxf(val, 0.0f), 1.0f);
   o.A = o.B = o.G = 0.0f;
-  if (want_coef && val >= 0.0f && val <= 1.0f) {  // clamp passes the gradient on [0,1] only
-    const float t = n2 * inv;                     // n2 / (d1 d2)
+  if (want_coef) {
+    // the clamp passes the gradient on [0,1] only, i.e. where it left the value alone: every coefficient carries
+    // the factor 1 / (d1 d2), so zeroing that one factor zeroes them all
+    const float ginv = (o.f == val) ? inv : 0.0f;
+    const float t = n2 * ginv;  // n2 / (d1 d2)
     const float inv_d1 = inv * d2, inv_d2 = inv * d1;
     const float a = -t * (muy - n1 * mux * inv_d1);
     const float bq = n1 * t * inv_d2;
-    const float g = -n1 * inv;
+    const float g = -n1 * ginv;
     o.A = a - bq * mux - g * muy;
     o.B = bq;
     o.G = g;
@@ -516,13 +519,19 @@ VSL_DEV void y_diffs(const float yw[3][4], float d[3][4]) {
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int j = 0; j < 4; ++j) d[r][j] = yw[r][j] - cy;
+  d[1][1] = 0.0f;  // the centre itself: spelled out so that no instruction is spent on it or on its products
 }
 VSL_DEV void y_stats_d(const float d[3][4], float sy[2], float syy[2]) {
   float c1[4], c2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    c1[j] = (d[0][j] + d[1][j]) + d[2][j];
-    c2[j] = fmaf(d[2][j], d[2][j], fmaf(d[1][j], d[1][j], d[0][j] * d[0][j]));
+    if (j == 1) {  // column of the centre: its middle entry is zero
+      c1[j] = d[0][j] + d[2][j];
+      c2[j] = fmaf(d[2][j], d[2][j], d[0][j] * d[0][j]);
+    } else {
+      c1[j] = (d[0][j] + d[1][j]) + d[2][j];
+      c2[j] = fmaf(d[2][j], d[2][j], fmaf(d[1][j], d[1][j], d[0][j] * d[0][j]));
+    }
   }
   float s1[2], s2[2];
   two_windows(c1, s1);
@@ -540,10 +549,17 @@ VSL_DEV void ssim_pair_d(const float xw[3][4], float cy, const float d[3][4], co
   float c1[4], c2[4], c3[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float e0 = xw[0][j] - cx, e1 = xw[1][j] - cx, e2 = xw[2][j] - cx;
-    c1[j] = (e0 + e1) + e2;
-    c2[j] = fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
-    c3[j] = fmaf(e2, d[2][j], fmaf(e1, d[1][j], e0 * d[0][j]));
+    const float e0 = xw[0][j] - cx, e2 = xw[2][j] - cx;
+    if (j == 1) {  // column of the centre: its middle entry is zero on both sides
+      c1[j] = e0 + e2;
+      c2[j] = fmaf(e2, e2, e0 * e0);
+      c3[j] = fmaf(e2, d[2][j], e0 * d[0][j]);
+    } else {
+      const float e1 = xw[1][j] - cx;
+      c1[j] = (e0 + e1) + e2;
+      c2[j] = fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
+      c3[j] = fmaf(e2, d[2][j], fmaf(e1, d[1][j], e0 * d[0][j]));
+    }
   }
   float sx[2], sxx[2], sxy[2];
   two_windows(c1, sx);
@@ -1171,7 +1187,12 @@ struct Fused {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-              for (int j = 0; j < NC; ++j) mf[s][i][j] = AVG ? (float)(sw[i][j] > 0.0f) : (float)(sw[i][j] == (float)s);
+              for (int j = 0; j < NC; ++j) {
+                if constexpr (!AVG && S == 2)  // the plane holds -1, 0 or 1: one instruction per mask
+                  mf[s][i][j] = s == 0 ? 1.0f - fabsf(sw[i][j]) : fmaxf(sw[i][j], 0.0f);
+                else
+                  mf[s][i][j] = AVG ? (float)(sw[i][j] > 0.0f) : (float)(sw[i][j] == (float)s);
+              }
         }
         // (row 1 of the masks is never folded, so mf[s][1][1 + k - J0] stays the mask of the pixel's own window)
         if (border) {

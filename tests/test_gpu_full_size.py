@@ -1,7 +1,7 @@
 """The benchmark configurations at their full sizes: HIP path (through the C-ABI) against the CPU
 oracle on the same seeded inputs, plus size-independent properties (shared identity minimum,
 forward-only heads, determinism).  Tolerances: loss 1e-5 relative, gradients 1e-5 relative (L2),
-identity_selection exact."""
+identity_selection exact wherever the two smallest candidates differ by more than float32 resolution."""
 import ctypes
 
 import numpy as np
@@ -48,6 +48,7 @@ def oracle_run(data, fids, B, H, W, head=0, warp_scale=1.0, scales=(0,), automas
     #  - the two smallest candidates of the per-pixel minimum (Trainer.py:598) closer than float32 resolution:
     #    the winner may differ, which changes the SSIM gradient of the 3x3 neighbourhood.
     amb = torch.zeros(B, H, W, dtype=torch.bool)
+    tie_px = torch.zeros(B, H, W, dtype=torch.bool)  # the per-pixel minimum itself is undecided in float32
     with torch.no_grad():
         cand, ident = [], []
         for f in fids[1:]:
@@ -62,9 +63,11 @@ def oracle_run(data, fids, B, H, W, head=0, warp_scale=1.0, scales=(0,), automas
         if cand.shape[1] > 1:
             two = torch.topk(cand, 2, dim=1, largest=False).values
             tie = ((two[:, 1] - two[:, 0]) < 2e-7).float().unsqueeze(1)
+            tie_px = tie[:, 0] > 0
             # with SSIM the winner of a pixel's window enters the gradient of its 3x3 neighbourhood; L1 alone is local
             amb |= (tie if no_ssim else torch.nn.functional.max_pool2d(tie, 3, 1, 1))[:, 0] > 0
     sel = outputs["identity_selection"] if automask else None
+    amb.tie_px = tie_px
     return losses, disp.grad, {f: poses[f].grad for f in fids[1:]}, sel, amb
 
 
@@ -148,8 +151,13 @@ def test_config_matches_oracle(name):
             assert max(errs) <= 1e-4, "masked grad_T[%s] relative errors %s" % (f, ["%.1e" % e for e in errs])
         assert rel(g2.numpy(), g2_ref.numpy()) <= TOL
     if sel_ref is not None:
-        flips = int((sel.numpy() != sel_ref.numpy()).sum())
-        assert flips == 0, "%d identity_selection flips" % flips
+        # identity_selection must be exact wherever float32 can decide the minimum: a flip is only tolerated at a pixel
+        # whose two smallest candidates are closer than 2e-7 in the float64 oracle (a handful per million at most)
+        differs = torch.from_numpy(sel.numpy() != sel_ref.numpy())
+        flips, undecided = int((differs & ~amb.tie_px).sum()), int((differs & amb.tie_px).sum())
+        print("identity_selection %s: %d flips at float32-undecidable pixels (of %d such pixels)" % (name, undecided, int(amb.tie_px.sum())))
+        assert flips == 0, "%d identity_selection flips at decidable pixels" % flips
+        assert undecided <= 2
 
 
 def _desc(abi, t, B, H, W, fids, head, flags, idmin=None, warp_scale=1.0):
