@@ -736,6 +736,18 @@ struct Fused {
   struct Block {
     int b, x0, y0;
   };
+  // The launcher sends every head that wants gradients through the full program and every other head through the
+  // forward-only one, so inside the full program the answer is known: phase 3 and the smoothness term take it as a
+  // constant (32 vector and 73 scalar instructions fewer per wave than with a run-time test).  Two places keep the
+  // test of HeadView::want_grad because the uniform branch holds the register allocation down: phase 2 around the
+  // coefficients (without it the two-source program needs two registers more than the 128 of four waves per SIMD),
+  // and the one-source mean-over-sources program as a whole (it sits at the 96 of five waves per SIMD).
+  static VSL_DEV bool wants_grad(const HeadView& hv) {
+    if constexpr (HALO == 2 && !(S == 1 && AVG))
+      return true;
+    else
+      return hv.want_grad != 0;
+  }
 
   // ---- phase 0: projection matrices (layers.py:189) and inv_K into wave-uniform registers -----------
   static VSL_DEV void phase0(const KParams& kp, const HeadView& hv, const Block& bk, int tid, ThreadState<S>& st) {
@@ -1143,7 +1155,7 @@ struct Fused {
     const size_t HW = (size_t)H * W;
 
     float g_disp[2] = {0.0f, 0.0f};
-    if (hv.want_grad) {
+    if (wants_grad(hv)) {
       // Reflection-padding fold (backward of layers.py:240,249-250): a window centred on the image
       // border counts twice for the pixel next to the border.  Only tiles that contain column 1 /
       // W-2 or row 1 / H-2 need the weights; the test is uniform over the workgroup.
@@ -1371,7 +1383,7 @@ struct Fused {
         }
     }
 
-    if (hv.want_grad) {
+    if (wants_grad(hv)) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
         if (ok[k]) store_f32_at(hv.gphoto + (size_t)bk.b * HW, row_major((unsigned)jy, (unsigned)W, (unsigned)(jx0 + k)) << 2, g_disp[k]);
@@ -1427,7 +1439,7 @@ struct Fused {
         if (t == 2) st.part[3] = fmaf(w, fabsf(diff), st.part[3]);
       }
       st.part[1] += d0;
-      if (hv.want_grad) store_f32_at(hv.gedge + (size_t)bk.b * HW, row_major((unsigned)jy, (unsigned)W, (unsigned)jx) << 2, e);
+      if (wants_grad(hv)) store_f32_at(hv.gedge + (size_t)bk.b * HW, row_major((unsigned)jy, (unsigned)W, (unsigned)jx) << 2, e);
     }
   }
 
