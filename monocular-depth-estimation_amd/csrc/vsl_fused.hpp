@@ -630,9 +630,10 @@ struct Ident {
     const int gy = bk.y0 + iy, gx0 = bk.x0 + 2 * ip;
     if (gy >= kp.H || gx0 >= kp.W) return;
     const int base = iy * RW + 2 * ip;
-    float fsum[S][2], lsum[S][2];
+    float err[S][2];  // photometric error, one channel's share after the other (see channel_error)
 #pragma unroll
-    for (int s = 0; s < S; ++s) fsum[s][0] = fsum[s][1] = lsum[s][0] = lsum[s][1] = 0.0f;
+    for (int s = 0; s < S; ++s) err[s][0] = err[s][1] = 0.0f;
+    const float w_l1 = kp.no_ssim ? 1.0f / 3.0f : kp.l1_w3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float yw[3][4], dy[3][4], sy[2], syy[2];
@@ -645,13 +646,13 @@ struct Ident {
       for (int s = 0; s < S; ++s) {
         float xw[3][4];
         load_win(lds + (3 + s * 3 + c) * PN, base, RW, xw);
-        lsum[s][0] += fabsf(yw[1][1] - xw[1][1]);
-        lsum[s][1] += fabsf(yw[1][2] - xw[1][2]);
+        err[s][0] = fmaf(w_l1, fabsf(yw[1][1] - xw[1][1]), err[s][0]);
+        err[s][1] = fmaf(w_l1, fabsf(yw[1][2] - xw[1][2]), err[s][1]);
         if (!kp.no_ssim) {
           SsimOut o[2];
           ssim_pair_d(xw, yw[1][1], dy, sy, syy, false, o);
-          fsum[s][0] += o[0].f;
-          fsum[s][1] += o[1].f;
+          err[s][0] = fmaf(kp.ssim_w3, o[0].f, err[s][0]);
+          err[s][1] = fmaf(kp.ssim_w3, o[1].f, err[s][1]);
         }
       }
     }
@@ -664,7 +665,7 @@ struct Ident {
       float best = INFINITY, idsum = 0.0f;
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        const float e = kp.no_ssim ? lsum[s][k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[s][k], kp.l1_w3 * lsum[s][k]);
+        const float e = err[s][k];
         if (AVG) {
           idsum += e;
         } else {
@@ -738,12 +739,19 @@ struct Fused {
   };
   // The launcher sends every head that wants gradients through the full program and every other head through the
   // forward-only one, so inside the full program the answer is known: phase 3 and the smoothness term take it as a
-  // constant (32 vector and 73 scalar instructions fewer per wave than with a run-time test).  Two places keep the
-  // test of HeadView::want_grad because the uniform branch holds the register allocation down: phase 2 around the
-  // coefficients (without it the two-source program needs two registers more than the 128 of four waves per SIMD),
-  // and the one-source mean-over-sources program as a whole (it sits at the 96 of five waves per SIMD).
+  // constant (32 vector and 73 scalar instructions fewer per wave than with a run-time test).  Where the constant
+  // would cost registers the program does not have, the uniform branch on HeadView::want_grad stays: the one-source
+  // mean-over-sources program as a whole (it sits at the 96 registers of five waves per SIMD), and phase 2 (the
+  // coefficients) of every program but the plain one- and two-source ones (the others spill with it).
   static VSL_DEV bool wants_grad(const HeadView& hv) {
     if constexpr (HALO == 2 && !(S == 1 && AVG))
+      return true;
+    else
+      return hv.want_grad != 0;
+  }
+  // the same question in phase 2 (coefficients or not): a constant only where the registers allow it
+  static VSL_DEV bool wants_coef(const HeadView& hv) {
+    if constexpr (HALO == 2 && !AVG && !OUT && S <= 2)
       return true;
     else
       return hv.want_grad != 0;
@@ -954,13 +962,16 @@ struct Fused {
     if constexpr (S <= 3) {
       // Channel by channel: the target window, its differences to the centre and its statistics are formed once and
       // serve every source frame; the per-source sums over the channels keep their order (c ascending).
-      float fsum[S][2], lsum[S][2];
+      // The error of (source, pixel) is accumulated channel by channel, one register each:
+      // 0.85/3 * SSIM term + 0.15/3 * |difference| per channel (Trainer.py:486-493; |difference| / 3 without SSIM).
+      float err[S][2];
+      constexpr float w_l1_only = 1.0f / 3.0f;
       // (!AVG) the first source's coefficients go to the LDS planes as they are formed -- they are what the planes
       // hold unless a later source wins -- so only the later sources' sets wait in registers for the decision
       constexpr int S0 = AVG ? 0 : 1;
       float cf[S - S0 > 0 ? S - S0 : 1][2][9];
 #pragma unroll
-      for (int s = 0; s < S; ++s) fsum[s][0] = fsum[s][1] = lsum[s][0] = lsum[s][1] = 0.0f;
+      for (int s = 0; s < S; ++s) err[s][0] = err[s][1] = 0.0f;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float yw[3][4], dy[3][4], sy[2], syy[2];
@@ -973,13 +984,13 @@ struct Fused {
         for (int s = 0; s < S; ++s) {
           float xw[3][4];
           load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
-          lsum[s][0] += fabsf(yw[1][1] - xw[1][1]);
-          lsum[s][1] += fabsf(yw[1][2] - xw[1][2]);
+          err[s][0] = fmaf(NOSSIM ? w_l1_only : kp.l1_w3, fabsf(yw[1][1] - xw[1][1]), err[s][0]);
+          err[s][1] = fmaf(NOSSIM ? w_l1_only : kp.l1_w3, fabsf(yw[1][2] - xw[1][2]), err[s][1]);
           SsimOut o[2];
           if (!NOSSIM) {
-            ssim_pair_d(xw, yw[1][1], dy, sy, syy, hv.want_grad != 0, o);
-            fsum[s][0] += o[0].f;
-            fsum[s][1] += o[1].f;
+            ssim_pair_d(xw, yw[1][1], dy, sy, syy, wants_coef(hv), o);
+            err[s][0] = fmaf(kp.ssim_w3, o[0].f, err[s][0]);
+            err[s][1] = fmaf(kp.ssim_w3, o[1].f, err[s][1]);
           } else {
             o[0].A = o[0].B = o[0].G = o[1].A = o[1].B = o[1].G = 0.0f;
           }
@@ -1003,7 +1014,7 @@ struct Fused {
       for (int s = 0; s < S; ++s) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          float e = NOSSIM ? lsum[s][k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[s][k], kp.l1_w3 * lsum[s][k]);
+          float e = err[s][k];
           e *= kp.warp_scale;
           if (AVG) {
             rsum[k] += e;
@@ -1045,21 +1056,21 @@ struct Fused {
       }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        float fsum[2] = {0.0f, 0.0f}, lsum[2] = {0.0f, 0.0f};
+        float err[2] = {0.0f, 0.0f};
         float cf[2][9];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           float yw[3][4], xw[3][4];
           load_win(lds + OFF_TGT + c * P2, base, R2W, yw);
           load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
-          lsum[0] += fabsf(yw[1][1] - xw[1][1]);
-          lsum[1] += fabsf(yw[1][2] - xw[1][2]);
+          err[0] = fmaf(NOSSIM ? 1.0f / 3.0f : kp.l1_w3, fabsf(yw[1][1] - xw[1][1]), err[0]);
+          err[1] = fmaf(NOSSIM ? 1.0f / 3.0f : kp.l1_w3, fabsf(yw[1][2] - xw[1][2]), err[1]);
           if (!NOSSIM) {
             SsimOut o[2];
             ssim_pair(xw, yw, sy[c], syy[c], hv.want_grad != 0, o);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-              fsum[k] += o[k].f;
+              err[k] = fmaf(kp.ssim_w3, o[k].f, err[k]);
               cf[k][c * 3 + 0] = o[k].A;
               cf[k][c * 3 + 1] = o[k].B;
               cf[k][c * 3 + 2] = o[k].G;
@@ -1072,7 +1083,7 @@ struct Fused {
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          float e = NOSSIM ? lsum[k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[k], kp.l1_w3 * lsum[k]);
+          float e = err[k];
           e *= kp.warp_scale;
           if (AVG) {
             rsum[k] += e;
@@ -1201,7 +1212,7 @@ struct Fused {
 #pragma unroll
               for (int j = 0; j < NC; ++j) {
                 if constexpr (!AVG && S == 2)  // the plane holds -1, 0 or 1: one instruction per mask
-                  mf[s][i][j] = s == 0 ? 1.0f - fabsf(sw[i][j]) : fmaxf(sw[i][j], 0.0f);
+                  mf[s][i][j] = s == 0 ? 1.0f - fabsf(sw[i][j]) : fminf(fmaxf(sw[i][j], 0.0f), 1.0f);  // clamp: one instruction
                 else
                   mf[s][i][j] = AVG ? (float)(sw[i][j] > 0.0f) : (float)(sw[i][j] == (float)s);
               }
@@ -1466,9 +1477,10 @@ struct Fused {
     bool warped_wins[2] = {false, false};
     float rsum[2] = {0.0f, 0.0f};
     // channel by channel, the target window's differences and statistics shared by all sources (as in phase 2)
-    float fsum[S][2], lsum[S][2];
+    float err[S][2];
 #pragma unroll
-    for (int s = 0; s < S; ++s) fsum[s][0] = fsum[s][1] = lsum[s][0] = lsum[s][1] = 0.0f;
+    for (int s = 0; s < S; ++s) err[s][0] = err[s][1] = 0.0f;
+    const float w_l1 = kp.no_ssim ? 1.0f / 3.0f : kp.l1_w3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float yw[3][4], dy[3][4], sy[2], syy[2];
@@ -1481,13 +1493,13 @@ struct Fused {
       for (int s = 0; s < S; ++s) {
         float xw[3][4];
         load_win(lds + OFF_WRP + (s * 3 + c) * P2, base, R2W, xw);
-        lsum[s][0] += fabsf(yw[1][1] - xw[1][1]);
-        lsum[s][1] += fabsf(yw[1][2] - xw[1][2]);
+        err[s][0] = fmaf(w_l1, fabsf(yw[1][1] - xw[1][1]), err[s][0]);
+        err[s][1] = fmaf(w_l1, fabsf(yw[1][2] - xw[1][2]), err[s][1]);
         if (!kp.no_ssim) {
           SsimOut o[2];
           ssim_pair_d(xw, yw[1][1], dy, sy, syy, false, o);
-          fsum[s][0] += o[0].f;
-          fsum[s][1] += o[1].f;
+          err[s][0] = fmaf(kp.ssim_w3, o[0].f, err[s][0]);
+          err[s][1] = fmaf(kp.ssim_w3, o[1].f, err[s][1]);
         }
       }
       VSL_SCHED_FENCE();
@@ -1496,7 +1508,7 @@ struct Fused {
     for (int s = 0; s < S; ++s) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        float e = kp.no_ssim ? lsum[s][k] * (1.0f / 3.0f) : fmaf(kp.ssim_w3, fsum[s][k], kp.l1_w3 * lsum[s][k]);
+        float e = err[s][k];
         e *= kp.warp_scale;
         if (AVG) {
           rsum[k] += e;
