@@ -54,3 +54,9 @@ for c in ids[:64]:
         cur += dlt; mx = max(mx, cur)
     conc.append(mx)
 print("max concurrent blocks on a CU (first 64 CUs):", sorted(set(conc)), "mean", np.mean(conc))
+# which SIMD of its CU each wave of a workgroup runs on (HW_ID bits 5:4)
+simd = ((buf[:, :, 11] & np.uint64(0xFFFFFFFF)).astype(np.int64) >> 4) & 0x3
+for w in range(NW):
+    print("wave %d on SIMD 0..3: %s" % (w, " ".join("%5d" % int((simd[:, w] == i).sum()) for i in range(4))))
+print("workgroups whose four waves sit on four different SIMDs: %d of %d" % (
+    int((np.sort(simd[:, :4], axis=1) == np.arange(4)).all(axis=1).sum()), simd.shape[0]))
