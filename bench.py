@@ -352,9 +352,10 @@ def main():
                          "frac_whole_call": alg_bytes / (head_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "copy_ceiling_GBs": ceiling,
                          "traffic_source": "committed rocprofv3 PMC passes (profiles/), not this run",
-                         "limiter": "not HBM but the vector ALU: the executed instructions of the four resident waves, priced "
-                                    "at their measured issue cost, fill 59 % (2 cycles each) to 87 % (class penalties) of a SIMD's time; "
-                                    "HBM runs at 18 % of peak (profiles/r02_valu_budget.txt, r02_pmc_pipes.txt)"},
+                         "limiter": "not HBM but instruction issue at four waves per SIMD (all the LDS and registers allow): the "
+                                    "vector instructions alone fill 66 % of the issue slots at 2 cycles each, scalar instructions and "
+                                    "branches weigh about as much per piece; HBM runs at 22 % of peak "
+                                    "(profiles/r02_pmc_pipes.txt, r02_valu_budget.txt)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(data, B, H, W, fids)
