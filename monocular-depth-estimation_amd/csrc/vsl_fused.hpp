@@ -901,9 +901,12 @@ struct Fused {
           if constexpr (CARRY) {
             // by every thread, also those of the halo rows that never use them: a branch here would end the basic
             // block, and the compiler then waits for each pair of gathers before it issues the next (measured +5 %)
+            // d/dix = (1-ty)(v01-v00) + ty(v11-v10), d/diy = (1-tx)(v10-v00) + tx(v11-v01): both are the difference
+            // along their own axis at the first tap plus the fraction along the other axis times the mixed difference
             const float v00 = a.lo, v01 = a.hi, v10 = b.lo, v11 = b.hi;
-            st.dp[k][s][c][0] = (1.0f - ty.t) * (v01 - v00) + ty.t * (v11 - v10);
-            st.dp[k][s][c][1] = (1.0f - txe) * (v10 - v00) + txe * (v11 - v01);
+            const float dx0 = v01 - v00, dy0 = v10 - v00, dxy = (v11 - v10) - dx0;
+            st.dp[k][s][c][0] = fmaf(ty.t, dxy, dx0);
+            st.dp[k][s][c][1] = fmaf(txe, dxy, dy0);
           }
         }
         if constexpr (CARRY) {
@@ -1345,8 +1348,9 @@ struct Fused {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               const float v00 = tv[k][c][0], v01 = tv[k][c][1], v10 = tv[k][c][2], v11 = tv[k][c][3];
-              const float dpx = (1.0f - ch.ty) * (v01 - v00) + ch.ty * (v11 - v10);
-              const float dpy = (1.0f - ch.tx) * (v10 - v00) + ch.tx * (v11 - v01);
+              const float dx0 = v01 - v00, dy0 = v10 - v00, dxy = (v11 - v10) - dx0;  // as in phase 1
+              const float dpx = fmaf(ch.ty, dxy, dx0);
+              const float dpy = fmaf(ch.tx, dxy, dy0);
               gix[k] = fmaf(g[s][k][c], dpx, gix[k]);
               giy[k] = fmaf(g[s][k][c], dpy, giy[k]);
             }
