@@ -355,6 +355,33 @@ def test_batch_offsets_just_below_the_index_limit():
         fused_view_synthesis_loss(big, imgs[0], [imgs[1], imgs[2]], K, inv_K, T, None)
 
 
+def test_loss_slots_of_a_large_batch_equal_the_mean_over_its_halves():
+    """The loss slots are means over the batch, assembled by whichever workgroup of the reduction arrives last: a
+    batch of 20 must give the mean of its two halves of 10, slot by slot, and the same gradients."""
+    import mde_amd.synth as synth
+    from mde_amd.ops import fused_view_synthesis_loss
+    B, H, W, fids = 20, 48, 160, [0, -1, 1]
+    data = synth.make_batch(B, H, W, fids, seed=23)
+    t = {k: v.to(DEV) for k, v in data.items() if torch.is_tensor(v)}
+
+    def run(sl):
+        d = t[("disp", 0)][sl].clone().requires_grad_(True)
+        poses = [t[("cam_T_cam", f)][sl].clone().requires_grad_(True) for f in fids[1:]]
+        losses, _ = fused_view_synthesis_loss(d, t[("image", 0)][sl], [t[("image", f)][sl] for f in fids[1:]], t["K"][sl],
+                                              t["inv_K"][sl], poses, t["noise"][sl])
+        losses[0].backward()
+        return losses.detach().double().cpu(), d.grad.cpu(), [p.grad.cpu() for p in poses]
+
+    l_all, g_all, gT_all = run(slice(0, B))
+    l_a, g_a, gT_a = run(slice(0, B // 2))
+    l_b, g_b, gT_b = run(slice(B // 2, B))
+    want = 0.5 * (l_a + l_b)
+    assert torch.all((l_all - want).abs() <= 1e-6 * want.abs() + 1e-12), (l_all, want)
+    assert rel(g_all.numpy() * 2, torch.cat([g_a, g_b]).numpy()) <= 1e-6
+    for s in range(2):
+        assert rel(gT_all[s].numpy() * 2, torch.cat([gT_a[s], gT_b[s]]).numpy()) <= 1e-6
+
+
 def test_in_kernel_tie_break_noise_is_standard_normal_and_keyed_by_seed():
     """With source == target the identity error is exactly 0, so vsl_identity_min returns min over sources of
     1e-5 * z (Trainer.py:587-590): with one source that is the noise itself.  The kernel's own generator (no noise
