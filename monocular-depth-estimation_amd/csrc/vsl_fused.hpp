@@ -74,9 +74,12 @@ constexpr int kTileW = 28, kIdentTileH = 12;
 #endif
 constexpr int fused_tile_h(int S, bool avg) { return (S <= 2 && !avg) ? VSL_TILE_H : VSL_TILE_H3; }
 // Tile width of the fused programs.  Three sources need 13 planes over R2: at 28 columns the LDS of a workgroup is
-// 42.4 KiB and three workgroups fit a CU, at 26 columns it is 39.7 KiB and four fit.
+// 42.4 KiB and three workgroups fit a CU, at 26 columns it is 39.7 KiB and four fit.  Three per CU is the faster
+// choice: the 168 registers of three waves per SIMD hold the 36 tap derivatives (Fused::CARRY, 147 used), which
+// saves phase 3 its second round of gathers, and a 28-wide tile has 7 % more outputs per workgroup (1024x320 b12
+// stereo: 253 -> 224 us).
 #ifndef VSL_TILE_W3
-#define VSL_TILE_W3 26
+#define VSL_TILE_W3 28
 #endif
 #ifndef VSL_TILE_W2
 #define VSL_TILE_W2 kTileW
@@ -373,11 +376,12 @@ VSL_DEV TileTaps tile_taps(float g, int n) {
   return tp;
 }
 
-// What phase 3 needs from phase 1 for one (pixel, source).  With up to two sources the six tap derivatives
-// d warped_c / d ix, d iy themselves stay in registers (ThreadState::dp, Fused::CARRY).  With more sources there
-// is no room for them: three registers say where the four bilinear taps are and what their fractions are, and
-// phase 3 fetches the taps again (cache hits, but 24 more gathers per thread through the vector L1, which is the
-// busiest unit of the kernel: without them the two-source kernel is 10 % faster) and rebuilds the derivatives.
+// What phase 3 needs from phase 1 for one (pixel, source).  Where the registers allow it (Fused::CARRY: up to
+// three sources) the six tap derivatives d warped_c / d ix, d iy themselves stay in registers (ThreadState::dp).
+// The other programs have no room for them: three registers say where the four bilinear taps are and what their
+// fractions are, and phase 3 fetches the taps again (cache hits, but 12 more gathers per thread and source through
+// the vector L1, which is the busiest unit of the kernel: without them the two-source kernel is 10 % faster) and
+// rebuilds the derivatives.
 struct Chain {
   float tx, ty;  // bilinear fractions; tx is relative to the texel pair below (1 when x0 = W-1)
   int packed;    // bits 0..27 offset of texel (y0, min(x0, W-2)) in the image plane: the 8 bytes there hold both
@@ -704,9 +708,10 @@ struct Fused {
   static constexpr int NSET = AVG ? S : 1;
   static constexpr int NPART = num_partials(S);
   // The full program keeps the tap derivatives of phase 1 in registers for phase 3 where the register budget of its
-  // workgroups per CU allows (two sources: 110 / 122 of 128 registers; one source with the mean over sources sits
-  // at the 96 of five workgroups per CU already); the others fetch the taps again.
-  static constexpr bool CARRY = HALO == 2 && (S == 2 || (S == 1 && !AVG));
+  // workgroups per CU allows (two sources: 128 of the 128 registers of four waves per SIMD; three sources: 147 of the
+  // 168 of three; one source with the mean over sources sits at the 96 of five workgroups per CU already); the
+  // others fetch the taps again.
+  static constexpr bool CARRY = HALO == 2 && (S == 2 || ((S == 1 || S == 3) && !AVG));
   static_assert(R2W / 2 <= ROWP && ROWP * R2H <= NT, "one R2 pair per thread, at most ROWP pairs per row");
   static_assert(P2 % 2 == 0 && P1 % 2 == 0, "planes must keep 8-byte alignment");
 
