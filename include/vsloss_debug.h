@@ -22,8 +22,9 @@ int vsl_debug_quot(const float* a, const float* b, float* q, long long n, void* 
 int vsl_debug_fused_occupancy(int S, int avg_reprojection);
 
 /* Runs vsl_loss_forward_heads `reps` times and returns in *avg_ms (host) the average duration of the fused tile
- * kernel alone, from HIP events recorded on `stream` directly around that launch.  Synchronises the host; creates
- * and destroys two events (the one place where the library touches an allocating runtime call). */
+ * kernel alone, from HIP events recorded on `stream` directly around that launch.  The calls are enqueued back to
+ * back, every launch between an event pair of its own, and the host waits once at the end (1 <= reps <= 4096).
+ * Creates and destroys 2 * reps events (the one place where the library touches an allocating runtime call). */
 int vsl_debug_time_fused(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, int reps, float* avg_ms,
                          void* stream);
 
