@@ -817,7 +817,17 @@ struct Fused {
   // pair is interior use that again in phase 3.
   static VSL_DEV void phase1(const KParams& kp, const HeadView& hv, const Block& bk, int tid, float* lds, ThreadState<S>& st) {
     st.photo = 0.0f;
-    const int trow = tid / ROWP, rx0 = 2 * (tid % ROWP);
+    // Which two positions of its row a thread warps.  The full program takes the horizontally adjacent pair
+    // (2 lane, 2 lane + 1) that the same thread differentiates in phase 3.  The forward-only program keeps nothing
+    // per thread, so it takes (lane, lane + ROWP) instead: the four lanes of a quad then gather for
+    // four adjacent pixels rather than every other one, and their taps fall into fewer cache lines.
+#if defined(VSL_PROBE_STRIDE1)
+    constexpr bool kStride1 = true;  // timing probe only: phase 3 then pairs the carried derivatives with the wrong pixels
+#else
+    constexpr bool kStride1 = HALO == 1;
+#endif
+    const int trow = tid / ROWP, rx0 = kStride1 ? tid % ROWP : 2 * (tid % ROWP);
+    constexpr int kStep = kStride1 ? ROWP : 1;
     if (trow >= R2H || rx0 >= R2W) {
       // No position for this thread (regions narrower than 2 * ROWP columns).  Phase 3 keeps every lane of a tile row
       // alive for its lane exchange and lets it fetch the taps its record names: the record must name a valid texel.
@@ -852,8 +862,10 @@ struct Fused {
     // rays share the y part: inv_K[i][1]*y is added after inv_K[i][0]*x in the reference's order
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int px = reflect_clamp(bk.x0 - HALO + rx0 + k, W);
-      const int p2 = ry * R2W + rx0 + k;
+      // (a second position past the row's end repeats the last one: same values into the same cells)
+      const int rx = kStride1 ? (rx0 + k * kStep < R2W ? rx0 + k * kStep : R2W - 1) : rx0 + k;
+      const int px = reflect_clamp(bk.x0 - HALO + rx, W);
+      const int p2 = ry * R2W + rx;
       const unsigned pix = row_major((unsigned)py, (unsigned)W, (unsigned)px);
       const float d = load_f32_at(dispb, pix << 2);
       lds[OFF_DSP + p2] = d;
@@ -863,7 +875,7 @@ struct Fused {
       // disp_to_depth and the back-projected ray, layers.py:21-25,163-169
       const float sd = VSL_FADD(kp.a_disp, VSL_FMUL(kp.c_disp, d));
       const float D = quot(1.0f, divisor(sd));
-      if constexpr (OUT) emit_depth(kp, hv, bk, ry, rx0 + k, pix, D);
+      if constexpr (OUT) emit_depth(kp, hv, bk, ry, rx, pix, D);
       const float fx = (float)px;
       float X[3];
 #pragma unroll
@@ -891,7 +903,7 @@ struct Fused {
         const float u = quot(cam[0], by_den), v = quot(cam[1], by_den);
         const float gx = VSL_FMUL(VSL_FSUB(quot(u, by_wm1), 0.5f), 2.0f);
         const float gy = VSL_FMUL(VSL_FSUB(quot(v, by_hm1), 0.5f), 2.0f);
-        if constexpr (OUT) emit_sample(kp, hv, bk, ry, rx0 + k, pix, s, gx, gy);
+        if constexpr (OUT) emit_sample(kp, hv, bk, ry, rx, pix, s, gx, gy);
         const TileTaps tx = tile_taps(gx, W), ty = tile_taps(gy, H);
         const float* sp = src_image(kp, s) + (size_t)bk.b * 3 * HW;
         // both x taps of a row come from one 8-byte load at min(x0, W-2)
@@ -909,7 +921,7 @@ struct Fused {
           const TexelPair a = load_texel_pair_at(pc, o0 << 2), b = load_texel_pair_at(pc, o1 << 2);
           const float wv = a.lo * w00 + a.hi * w01 + b.lo * w10 + b.hi * w11;
           lds[OFF_WRP + (s * 3 + c) * P2 + p2] = wv;
-          if constexpr (OUT) emit_color(kp, hv, bk, ry, rx0 + k, pix, s, c, wv);
+          if constexpr (OUT) emit_color(kp, hv, bk, ry, rx, pix, s, c, wv);
           if constexpr (CARRY) {
             // by every thread, also those of the halo rows that never use them: a branch here would end the basic
             // block, and the compiler then waits for each pair of gathers before it issues the next (measured +5 %)
