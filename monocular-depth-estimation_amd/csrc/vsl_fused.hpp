@@ -226,7 +226,12 @@ VSL_DEV unsigned long long noise_key(unsigned long long seed, unsigned plane) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-VSL_DEV float hash_normal(unsigned long long key, unsigned pix) {
+// Both outputs of one Box-Muller transform: two independent N(0,1) values per (key, pixel).  The identity tile program
+// draws the noise of two source planes of a pixel from one transform (one hash, logarithm and square root for both).
+struct Normal2 {
+  float a, b;
+};
+VSL_DEV Normal2 hash_normal2(unsigned long long key, unsigned pix) {
   unsigned x = pix ^ (unsigned)key;
   x ^= x >> 16;
   x *= 0x7FEB352Du;
@@ -239,11 +244,14 @@ VSL_DEV float hash_normal(unsigned long long key, unsigned pix) {
   const float u2 = (float)(y >> 8) * (1.0f / 16777216.0f);           // [0,1)
 #if defined(__HIP_DEVICE_COMPILE__)
   // -2 ln(u1) = -2 ln(2) log2(u1)
-  return __builtin_amdgcn_sqrtf(-1.38629436112f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+  const float r = __builtin_amdgcn_sqrtf(-1.38629436112f * __builtin_amdgcn_logf(u1));
+  return Normal2{r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2)};
 #else
-  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
+  const float r = sqrtf(-2.0f * logf(u1));
+  return Normal2{r * cosf(6.28318530718f * u2), r * sinf(6.28318530718f * u2)};
 #endif
 }
+VSL_DEV float hash_normal(unsigned long long key, unsigned pix) { return hash_normal2(key, pix).a; }
 
 // Projection matrix P = (K @ T)[:3,:] with separate multiply and add roundings
 // (what a batched 4x4 matmul on the CPU produces), layers.py:189.
@@ -667,15 +675,28 @@ struct Ident {
       if (gx0 + k >= kp.W) continue;
       const size_t pix = (size_t)gy * kp.W + gx0 + k;
       float best = INFINITY, idsum = 0.0f;
+      float zs[S];  // (!AVG) tie-break noise of every source plane at this pixel
+      if (!AVG) {
+        if (kp.noise) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) zs[s] = kp.noise[(size_t)(bk.b * NI + s) * HW + pix];
+        } else {
+          // planes 2j and 2j+1 share one transform, keyed by the even plane
+#pragma unroll
+          for (int s = 0; s < S; s += 2) {
+            const Normal2 z2 = hash_normal2(noise_key(kp.seed, (unsigned)(bk.b * NI + s)), (unsigned)pix);
+            zs[s] = z2.a;
+            if (s + 1 < S) zs[s + 1] = z2.b;
+          }
+        }
+      }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         const float e = err[s][k];
         if (AVG) {
           idsum += e;
         } else {
-          const unsigned plane = (unsigned)(bk.b * NI + s);
-          const float z = kp.noise ? kp.noise[(size_t)plane * HW + pix] : hash_normal(noise_key(kp.seed, plane), (unsigned)pix);
-          const float v = fmaf(z, 0.00001f, e);
+          const float v = fmaf(zs[s], 0.00001f, e);
           if (v < best) best = v;
         }
       }

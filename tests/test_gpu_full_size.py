@@ -3,6 +3,7 @@ oracle on the same seeded inputs, plus size-independent properties (shared ident
 forward-only heads, determinism).  Tolerances: loss 1e-5 relative, gradients 1e-5 relative (L2),
 identity_selection exact wherever the two smallest candidates differ by more than float32 resolution."""
 import ctypes
+import math
 
 import numpy as np
 import pytest
@@ -414,6 +415,30 @@ def test_in_kernel_tie_break_noise_is_standard_normal_and_keyed_by_seed():
     for a, b in ((z[:, :, 1:], z[:, :, :-1]), (z[:, 1:], z[:, :-1]), (z[1:], z[:-1]), (z, z_other)):
         c = float((a * b).mean())
         assert abs(c) < 5.0 / a.numel() ** 0.5, c
+
+
+def test_in_kernel_noise_of_two_source_planes_is_independent():
+    """Two sources equal to the target: vsl_identity_min returns 1e-5 * min(z0, z1).  The kernel draws the noise of a
+    pixel's two source planes from one Box-Muller transform (cosine and sine branch); the minimum of two independent
+    N(0,1) values has mean -1/sqrt(pi) and variance 1 - 1/pi (correlated planes would move both towards 0 and 1)."""
+    import mde_amd._abi as abi
+    import mde_amd.synth as synth
+    B, H, W, fids = 4, 192, 640, [0, -1, 1]
+    data = synth.make_batch(B, H, W, fids, seed=17)
+    t = {k: v.to(DEV) for k, v in data.items() if torch.is_tensor(v)}
+    t[("image", -1)] = t[("image", 0)].clone()
+    t[("image", 1)] = t[("image", 0)].clone()
+    d = _desc(abi, t, B, H, W, fids, 0, abi.FLAG_AUTOMASK)
+    d.noise, d.seed = None, 5
+    out = torch.empty(B, H, W, device=DEV)
+    abi.check(abi.lib.vsl_identity_min(ctypes.byref(d), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    m = (out.double() / 1e-5).cpu()
+    n = m.numel()
+    assert abs(float(m.mean()) + math.pi ** -0.5) < 5.0 / n ** 0.5
+    assert abs(float(m.var()) - (1.0 - 1.0 / math.pi)) < 0.01
+    c = float(((m[:, :, 1:] - m.mean()) * (m[:, :, :-1] - m.mean())).mean())
+    assert abs(c) < 5.0 / n ** 0.5, c
 
 
 def test_directional_derivative_agrees_with_the_gradient_at_benchmark_size():

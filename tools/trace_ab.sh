@@ -12,7 +12,7 @@ rc=$?; tail -2 $O/pytest.log
 for l in "$@"; do
   if [ "$l" = default ]; then unset VSL_LIBRARY; else export VSL_LIBRARY=$PWD/tools/$l; fi
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$l -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/$l.log 2>&1 || { tail -5 $O/$l.log; exit 1; }
-  echo "== $l"; find $O/$l -name '*kernel_stats.csv' -exec cat {} \; | grep vsl_ | awk -F, '{printf "%-60s calls %s avg_ns %s\n", substr($1,1,60), $2, $4}'
-  tail -1 $O/$l.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('step_us %.1f frames/s %.0f'%(d['ms_per_step']*1e3, d['value']))"
+  echo "== $l"; python tools/kernel_stats.py $O/$l
+  grep '^{' $O/$l.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('step_us %.1f frames/s %.0f'%(d['ms_per_step']*1e3, d['value']))"
   find $O/$l -name '*kernel_trace.csv' -delete
 done
