@@ -1,7 +1,7 @@
 """GPU parity of the fused HIP loss (through the C-ABI / autograd binding) against
 the golden fixtures produced by the reference, and against the CPU oracle on
 seeded inputs.  Tolerance: 1e-5 relative on the loss, 1e-5 relative L2 on every
-gradient (float32 path, BASELINE.json north_star)."""
+gradient (the float32 path's stated tolerance)."""
 import numpy as np
 import pytest
 import torch
