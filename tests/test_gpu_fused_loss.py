@@ -121,6 +121,52 @@ def test_ragged_shapes_against_oracle(shape):
     assert np.array_equal(ident.cpu().numpy(), outputs["identity_selection"].numpy())
 
 
+def test_every_image_of_a_batch_has_its_own_intrinsics_and_poses():
+    """K and inv_K are [B,4,4] tensors in the reference (data_loaders.py:384-399 builds them per sample,
+    layers.py:163,189 multiply them per batch element): a batch whose images differ in focal length and principal point
+    (as after a per-sample crop or resize) against the CPU oracle, two tiles wide and three high, mono + stereo."""
+    import mde_amd.synth as synth
+    from mde_amd.ops import fused_view_synthesis_loss
+    from oracle import vsl_oracle as O
+    B, H, W = 3, 30, 44
+    fids = [0, -1, 1, "s"]
+    data = synth.make_batch(B, H, W, fids, seed=321, blur=3)
+    K = data["K"].clone()
+    for b in range(B):
+        K[b, 0, 0] *= 1.0 + 0.15 * b      # fx
+        K[b, 1, 1] *= 1.0 - 0.10 * b      # fy
+        K[b, 0, 2] += 1.5 * b             # cx
+        K[b, 1, 2] -= 0.75 * b            # cy
+    inv_K = torch.from_numpy(np.linalg.pinv(K.numpy())).float().contiguous()
+    dev = torch.device("cuda:0")
+    T = lambda f: data["stereo_T"] if f == "s" else data[("cam_T_cam", f)]
+    disp = data[("disp", 0)].to(dev).requires_grad_(True)
+    poses = [T(f).to(dev).requires_grad_(True) for f in fids[1:]]
+    losses, ident = fused_view_synthesis_loss(
+        disp, data[("image", 0)].to(dev), [data[("image", f)].to(dev) for f in fids[1:]],
+        K.to(dev), inv_K.to(dev), poses, data["noise"].to(dev))
+    losses[0].backward()
+    cfg = O.LossConfig(frame_ids=fids, height=H, width=W, automask=True)
+    inputs = {"K": K, "inv_K": inv_K}
+    for f in fids:
+        inputs[("image", f)] = data[("image", f)].double()
+    d_ref = data[("disp", 0)].clone().requires_grad_(True)
+    outputs = {("disp", 0): d_ref}
+    ref_T = {}
+    for f in fids[1:]:
+        ref_T[f] = T(f).clone().requires_grad_(True)
+        if f == "s":
+            inputs["stereo_T"] = ref_T[f]
+        else:
+            outputs[("cam_T_cam", f)] = ref_T[f]
+    ref = O.loss_forward_backward(inputs, outputs, cfg, data["noise"])
+    assert abs(losses[0].item() - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
+    assert rel(disp.grad.cpu().numpy(), d_ref.grad.numpy()) <= TOL
+    for i, f in enumerate(fids[1:]):
+        assert rel(poses[i].grad.cpu().numpy(), ref_T[f].grad.numpy()) <= 2e-5
+    assert np.array_equal(ident.cpu().numpy(), outputs["identity_selection"].numpy())
+
+
 def test_invalid_arguments_raise():
     from mde_amd.ops import fused_view_synthesis_loss
     dev = torch.device("cuda:0")
