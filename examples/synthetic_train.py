@@ -82,6 +82,100 @@ def build_models(opt, tiny: bool, dev):
             "pose": N.PoseDecoder(len(opt.frame_ids), len(opt.frame_ids) - 1).to(dev)}
 
 
+def run(dev, rank, world, *, steps=20, warmup=5, batch=12, height=192, width=640, tiny=False,
+        channels_last=False, amp=False, ddp=False, host_staged=False):
+    """`warmup` untimed and `steps` timed optimizer steps on device `dev`; with `ddp` the process group must
+    already exist.  Returns the result record (every rank; the timing is the maximum over ranks).
+    `host_staged`: gradient buckets are averaged through host memory (for the gloo rehearsal with several ranks on
+    one card, where gloo stalls on large device tensors); RCCL runs reduce the device buckets directly."""
+    import mde_amd.synth as synth
+    from mde_amd.trainer_step import NetworkPass, TrainStep
+
+    opt = types.SimpleNamespace(
+        scales=[0, 1, 2, 3], frame_ids=[0, -1, 1], height=height, width=width, min_depth=0.1, max_depth=100.0,
+        v1_multiscale=False, disable_automasking=False, avg_reprojection=False, no_ssim=False,
+        disparity_smoothness=1e-3, pose_model_type="shared", pose_model_input="all", learning_rate=1e-4)
+    torch.manual_seed(0)
+    net = NetworkPass(opt, build_models(opt, tiny, dev))
+    if channels_last:
+        net = net.to(memory_format=torch.channels_last)
+    params = list(net.parameters())
+    n_params = sum(p.numel() for p in params)
+    if ddp:
+        net = nn.parallel.DistributedDataParallel(net, device_ids=[dev.index])
+        if host_staged:
+            def staged(_state, bucket):
+                buf = bucket.buffer()
+                host = buf.cpu()
+                torch.distributed.all_reduce(host)
+                buf.copy_(host / world)
+                fut = torch.futures.Future()
+                fut.set_result(buf)
+                return fut
+            net.register_comm_hook(None, staged)
+    # every decoder scale is a disparity head of the loss (upsampled to full resolution, Trainer.py:431)
+    step = TrainStep(opt, net, torch.optim.Adam(params, opt.learning_rate), per_scale=not tiny,
+                     autocast_dtype=torch.bfloat16 if amp else None)
+
+    data = synth.make_batch(batch, height, width, opt.frame_ids, seed=100 + rank)
+    inputs = {"K": data["K"].to(dev), "inv_K": data["inv_K"].to(dev)}
+    for f in opt.frame_ids:
+        inputs[("image", f)] = data[("image", f)].to(dev)
+        inputs[("image_aug", f)] = inputs[("image", f)]
+
+    # share of the loss in a step: events around the library's forward and backward calls
+    import mde_amd.ops as ops
+    marks = []
+    saved = {}
+
+    def timed(fn):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            marks.append((e0, e1))
+            return r
+        return wrapper
+
+    for cls in (ops._FusedLossFn, ops._FusedHeadsFn):
+        saved[cls] = (cls.forward, cls.backward)
+        cls.forward = staticmethod(timed(cls.forward))
+        cls.backward = staticmethod(timed(cls.backward))
+    try:
+        first = None
+        for i in range(warmup + steps):
+            if i == warmup:
+                if ddp:
+                    torch.distributed.barrier()
+                torch.cuda.synchronize(dev)
+                marks.clear()
+                t0 = time.perf_counter()
+            _, losses = step.train_step(inputs)
+            if i == 0:
+                first = losses["loss"].item()
+        if ddp:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    finally:
+        for cls, (f, b) in saved.items():
+            cls.forward, cls.backward = staticmethod(f), staticmethod(b)
+    last = losses["loss"].item()
+    loss_ms = sum(a.elapsed_time(b) for a, b in marks) / steps
+    t = torch.tensor([dt], device=dev)
+    if ddp:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    ms = 1e3 * t.item() / steps
+    return {"what": "synthetic end-to-end training step, %s networks, %d params" % (
+                "stand-in" if tiny else "ResNet-18 encoder + depth decoder + pose decoder", n_params),
+            "n_gpus": world, "ddp": ddp, "network_dtype": "bf16 autocast" if amp else "f32", "steps": steps,
+            "warmup": warmup, "batch_per_gpu": batch, "frames_per_s": world * batch * steps / t.item(), "ms_per_step": ms,
+            "loss_ms_per_step": loss_ms, "loss_share_of_step": loss_ms / ms,
+            "grad_allreduce_bytes_per_step": 4 * n_params if ddp else 0,
+            "first_loss": first, "last_loss": last}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
@@ -107,78 +201,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         kw = {"device_id": dev} if args.backend == "nccl" else {}
         torch.distributed.init_process_group(args.backend, rank=rank, world_size=world, **kw)
-
-    import mde_amd.synth as synth
-    from mde_amd.trainer_step import NetworkPass, TrainStep
-
-    opt = types.SimpleNamespace(
-        scales=[0, 1, 2, 3], frame_ids=[0, -1, 1], height=args.height, width=args.width, min_depth=0.1, max_depth=100.0,
-        v1_multiscale=False, disable_automasking=False, avg_reprojection=False, no_ssim=False,
-        disparity_smoothness=1e-3, pose_model_type="shared", pose_model_input="all", learning_rate=1e-4)
-    torch.manual_seed(0)
-    net = NetworkPass(opt, build_models(opt, args.tiny, dev))
-    if args.channels_last:
-        net = net.to(memory_format=torch.channels_last)
-    params = list(net.parameters())
-    n_params = sum(p.numel() for p in params)
-    if ddp:
-        net = nn.parallel.DistributedDataParallel(net, device_ids=[dev.index])
-    # every decoder scale is a disparity head of the loss (upsampled to full resolution, Trainer.py:431)
-    step = TrainStep(opt, net, torch.optim.Adam(params, opt.learning_rate), per_scale=not args.tiny,
-                     autocast_dtype=torch.bfloat16 if args.amp else None)
-
-    data = synth.make_batch(args.batch, args.height, args.width, opt.frame_ids, seed=100 + rank)
-    inputs = {"K": data["K"].to(dev), "inv_K": data["inv_K"].to(dev)}
-    for f in opt.frame_ids:
-        inputs[("image", f)] = data[("image", f)].to(dev)
-        inputs[("image_aug", f)] = inputs[("image", f)]
-
-    # share of the loss in a step: events around the library's forward and backward calls
-    import mde_amd.ops as ops
-    marks = []
-
-    def timed(fn):
-        def wrapper(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn(*a, **k)
-            e1.record()
-            marks.append((e0, e1))
-            return r
-        return wrapper
-
-    for cls in (ops._FusedLossFn, ops._FusedHeadsFn):
-        cls.forward = staticmethod(timed(cls.forward))
-        cls.backward = staticmethod(timed(cls.backward))
-
-    first = None
-    for i in range(args.warmup + args.steps):
-        if i == args.warmup:
-            if ddp:
-                torch.distributed.barrier()
-            torch.cuda.synchronize()
-            marks.clear()
-            t0 = time.perf_counter()
-        _, losses = step.train_step(inputs)
-        if i == 0:
-            first = losses["loss"].item()
-    if ddp:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    last = losses["loss"].item()
-    loss_ms = sum(a.elapsed_time(b) for a, b in marks) / args.steps
-    t = torch.tensor([dt], device=dev)
-    if ddp:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    out = run(dev, rank, world, steps=args.steps, warmup=args.warmup, batch=args.batch, height=args.height,
+              width=args.width, tiny=args.tiny, channels_last=args.channels_last, amp=args.amp, ddp=ddp,
+              host_staged=ddp and args.backend != "nccl")
     if rank == 0:
-        ms = 1e3 * t.item() / args.steps
-        print(json.dumps({"what": "synthetic end-to-end training step, %s networks, %d params" % (
-                              "stand-in" if args.tiny else "ResNet-18 encoder + depth decoder + pose decoder", n_params),
-                          "n_gpus": world, "ddp": ddp, "network_dtype": "bf16 autocast" if args.amp else "f32", "steps": args.steps, "batch_per_gpu": args.batch,
-                          "frames_per_s": world * args.batch * args.steps / t.item(), "ms_per_step": ms,
-                          "loss_ms_per_step": loss_ms, "loss_share_of_step": loss_ms / ms,
-                          "first_loss": first, "last_loss": last}))
+        print(json.dumps(out))
     if ddp:
         torch.distributed.destroy_process_group()
 

@@ -25,33 +25,67 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+# Descriptor templates per call signature.  Filling a ctypes structure costs a fraction of a microsecond per field and a
+# step touches ~80 of them; a training loop calls with the same shapes and options every step, so the constant fields
+# are filled once per signature and every call copies the template (one memcpy) and sets only the pointers.  The
+# copies are per call: a forward of the same signature between another call's forward and backward cannot disturb it.
+_PLANS = {}
+
+
+class _Plan:
+    __slots__ = ("desc", "heads", "nbytes", "stride")
+
+
+def _loss_plan(B, H, W, S, flags, cfg, scale_weights):
+    key = ("single", B, H, W, S, flags, cfg["min_depth"], cfg["max_depth"], cfg["warp_scale"], cfg["inv_num_scales"],
+           tuple(scale_weights))
+    plan = _PLANS.get(key)
+    if plan is None:
+        plan = _Plan()
+        desc = _abi.LossDesc()
+        desc.B, desc.H, desc.W, desc.S = B, H, W, S
+        desc.flags = flags
+        desc.min_depth, desc.max_depth, desc.eps = cfg["min_depth"], cfg["max_depth"], 1e-7
+        desc.ssim_weight, desc.l1_weight, desc.warp_scale = 0.85, 0.15, cfg["warp_scale"]
+        desc.n_scales = len(scale_weights)
+        for i, w in enumerate(scale_weights):
+            desc.scale_weight[i] = w
+        desc.inv_num_scales = cfg["inv_num_scales"]
+        plan.desc, plan.heads = desc, None
+        plan.nbytes = _abi.lib.vsl_loss_workspace_bytes(ctypes.byref(desc))
+        plan.stride = (plan.nbytes + 255) // 256 * 256
+        if len(_PLANS) > 256:       # signatures that keep changing (a sweep over shapes): start over
+            _PLANS.clear()
+        _PLANS[key] = plan
+    return plan
+
+
+def _set_common_pointers(desc, cfg, poses, keep):
+    S = len(poses)
+    desc.target = cfg["target"].data_ptr()
+    desc.K, desc.inv_K = cfg["K"].data_ptr(), cfg["inv_K"].data_ptr()
+    for s in range(S):
+        desc.source[s] = cfg["sources"][s].data_ptr()
+        desc.T[s] = poses[s].data_ptr()
+    if cfg["noise"] is not None:
+        desc.noise = cfg["noise"].data_ptr()
+        keep.append(cfg["noise"])
+    desc.seed = cfg["seed"]
+
+
 class _FusedLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, disp, *poses):
-        desc = _abi.LossDesc()
         B, _, H, W = disp.shape
         S = len(poses)
-        desc.B, desc.H, desc.W, desc.S = B, H, W, S
-        desc.flags = cfg["flags"] | (0 if cfg["want_grad"] else _abi.FLAG_NO_GRAD)
-        desc.min_depth, desc.max_depth, desc.eps = cfg["min_depth"], cfg["max_depth"], 1e-7
-        desc.ssim_weight, desc.l1_weight, desc.warp_scale = 0.85, 0.15, cfg["warp_scale"]
-        sw = cfg["scale_weights"]
-        desc.n_scales = len(sw)
-        for i, w in enumerate(sw):
-            desc.scale_weight[i] = w
-        desc.inv_num_scales = cfg["inv_num_scales"]
+        flags = cfg["flags"] | (0 if cfg["want_grad"] else _abi.FLAG_NO_GRAD)
+        plan = _loss_plan(B, H, W, S, flags, cfg, cfg["scale_weights"])
+        desc = _abi.LossDesc.from_buffer_copy(plan.desc)
+        nbytes = plan.nbytes
         keep = [disp, cfg["target"], cfg["K"], cfg["inv_K"]] + list(cfg["sources"]) + list(poses)
-        desc.disp, desc.target = disp.data_ptr(), cfg["target"].data_ptr()
-        desc.K, desc.inv_K = cfg["K"].data_ptr(), cfg["inv_K"].data_ptr()
-        for s in range(S):
-            desc.source[s] = cfg["sources"][s].data_ptr()
-            desc.T[s] = poses[s].data_ptr()
-        if cfg["noise"] is not None:
-            desc.noise = cfg["noise"].data_ptr()
-            keep.append(cfg["noise"])
-        desc.seed = cfg["seed"]
+        desc.disp = disp.data_ptr()
+        _set_common_pointers(desc, cfg, poses, keep)
 
-        nbytes = _abi.lib.vsl_loss_workspace_bytes(ctypes.byref(desc))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=disp.device)
         losses = torch.empty(_abi.LOSS_SLOTS, dtype=torch.float32, device=disp.device)
         automask = bool(cfg["flags"] & _abi.FLAG_AUTOMASK)
@@ -90,18 +124,19 @@ class _FusedLossFn(torch.autograd.Function):
         B, H, W, S = ctx.shape
         dev = ctx.ws.device
         need = ctx.needs_input_grad  # (cfg, disp, *poses)
-        g_losses = g_losses.contiguous().float()
+        if g_losses.dtype != torch.float32 or not g_losses.is_contiguous():
+            g_losses = g_losses.contiguous().float()
         grad_disp = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev) if need[1] else None
-        grad_T = [torch.empty(B, 4, 4, dtype=torch.float32, device=dev) if need[2 + s] else None for s in range(S)]
+        grad_T = torch.empty(S, B, 4, 4, dtype=torch.float32, device=dev) if any(need[2:2 + S]) else None
         ptrs = (ctypes.c_void_p * _abi.MAX_SOURCES)()
         for s in range(S):
-            ptrs[s] = grad_T[s].data_ptr() if grad_T[s] is not None else None
+            ptrs[s] = grad_T[s].data_ptr() if need[2 + s] else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(_abi.lib.vsl_loss_backward(ctypes.byref(ctx.desc), ctx.ws.data_ptr(), ctx.nbytes,
                                               g_losses.data_ptr(),
                                               grad_disp.data_ptr() if grad_disp is not None else None,
                                               ptrs, stream))
-        return (None, grad_disp) + tuple(grad_T)
+        return (None, grad_disp) + tuple(grad_T[s] if need[2 + s] else None for s in range(S))
 
 
 def fused_view_synthesis_loss(disp: torch.Tensor, target: torch.Tensor, sources: Sequence[torch.Tensor],
@@ -150,78 +185,106 @@ def fused_view_synthesis_loss(disp: torch.Tensor, target: torch.Tensor, sources:
     return (out[0], (out[1] if automask else None)) + tuple(out[2:])
 
 
+def _heads_plan(B, H, W, S, n_heads, flags, cfg):
+    key = ("heads", B, H, W, S, n_heads, flags, cfg["min_depth"], cfg["max_depth"], cfg["warp_scale"],
+           cfg["inv_num_scales"], tuple(cfg["forward_only"]), tuple(tuple(w) for w in cfg["scale_weights"]))
+    plan = _PLANS.get(key)
+    if plan is None:
+        plan = _Plan()
+        desc = _abi.LossDesc()
+        desc.B, desc.H, desc.W, desc.S = B, H, W, S
+        desc.flags = flags
+        desc.min_depth, desc.max_depth, desc.eps = cfg["min_depth"], cfg["max_depth"], 1e-7
+        desc.ssim_weight, desc.l1_weight, desc.warp_scale = 0.85, 0.15, cfg["warp_scale"]
+        desc.n_scales, desc.inv_num_scales = 1, cfg["inv_num_scales"]
+        plan.desc = desc
+        plan.nbytes = _abi.lib.vsl_loss_workspace_bytes(ctypes.byref(desc))
+        plan.stride = (plan.nbytes + 255) // 256 * 256
+        heads = (_abi.Head * n_heads)()
+        for h in range(n_heads):
+            hd = heads[h]
+            hd.workspace_bytes = plan.nbytes
+            hd.flags = _abi.HEAD_NO_GRAD if cfg["forward_only"][h] else 0
+            sw = cfg["scale_weights"][h]
+            hd.n_scales = len(sw)
+            for i, w in enumerate(sw):
+                hd.scale_weight[i] = w
+        plan.heads = heads
+        if len(_PLANS) > 256:
+            _PLANS.clear()
+        _PLANS[key] = plan
+    return plan
+
+
 class _FusedHeadsFn(torch.autograd.Function):
     """Several disparity heads over the same images and poses in one launch (vsl_loss_*_heads)."""
 
     @staticmethod
     def forward(ctx, cfg, n_heads, *tensors):
         disps, poses = tensors[:n_heads], tensors[n_heads:]
-        desc = _abi.LossDesc()
         B, _, H, W = disps[0].shape
         S = len(poses)
-        desc.B, desc.H, desc.W, desc.S = B, H, W, S
-        desc.flags = cfg["flags"] | (0 if cfg["want_grad"] else _abi.FLAG_NO_GRAD)
-        desc.min_depth, desc.max_depth, desc.eps = cfg["min_depth"], cfg["max_depth"], 1e-7
-        desc.ssim_weight, desc.l1_weight, desc.warp_scale = 0.85, 0.15, cfg["warp_scale"]
-        desc.n_scales, desc.inv_num_scales = 1, cfg["inv_num_scales"]
-        desc.target = cfg["target"].data_ptr()
-        desc.K, desc.inv_K = cfg["K"].data_ptr(), cfg["inv_K"].data_ptr()
+        flags = cfg["flags"] | (0 if cfg["want_grad"] else _abi.FLAG_NO_GRAD)
+        plan = _heads_plan(B, H, W, S, n_heads, flags, cfg)
+        desc = _abi.LossDesc.from_buffer_copy(plan.desc)
+        heads = type(plan.heads).from_buffer_copy(plan.heads)
         keep = list(disps) + list(poses) + [cfg["target"], cfg["K"], cfg["inv_K"]] + list(cfg["sources"])
-        for s in range(S):
-            desc.source[s] = cfg["sources"][s].data_ptr()
-            desc.T[s] = poses[s].data_ptr()
-        if cfg["noise"] is not None:
-            desc.noise = cfg["noise"].data_ptr()
-            keep.append(cfg["noise"])
-        desc.seed = cfg["seed"]
+        _set_common_pointers(desc, cfg, poses, keep)
         dev = disps[0].device
-        desc.disp = disps[0].data_ptr()      # only read by the workspace query
-        nbytes = _abi.lib.vsl_loss_workspace_bytes(ctypes.byref(desc))
         automask = bool(cfg["flags"] & _abi.FLAG_AUTOMASK)
-        heads = (_abi.Head * n_heads)()
-        ws = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(n_heads)]
+        # one allocation for the workspaces of all heads (each a 256-byte-aligned slice), one for the outputs
+        ws = torch.empty(n_heads * plan.stride, dtype=torch.uint8, device=dev)
         losses = torch.empty(n_heads, _abi.LOSS_SLOTS, dtype=torch.float32, device=dev)
         ident = torch.empty(n_heads if automask else 0, B, H, W, dtype=torch.float32, device=dev)
+        ws_ptr, loss_ptr, ident_ptr = ws.data_ptr(), losses.data_ptr(), ident.data_ptr()
         for h in range(n_heads):
             hd = heads[h]
-            hd.disp, hd.workspace, hd.workspace_bytes = disps[h].data_ptr(), ws[h].data_ptr(), nbytes
-            hd.losses = losses[h].data_ptr()
-            hd.identity_selection = ident[h].data_ptr() if automask else None
-            hd.flags = _abi.HEAD_NO_GRAD if cfg["forward_only"][h] else 0
-            sw = cfg["scale_weights"][h]
-            hd.n_scales = len(sw)
-            for i, w in enumerate(sw):
-                hd.scale_weight[i] = w
+            hd.disp, hd.workspace = disps[h].data_ptr(), ws_ptr + h * plan.stride
+            hd.losses = loss_ptr + 4 * _abi.LOSS_SLOTS * h
+            hd.identity_selection = ident_ptr + 4 * B * H * W * h if automask else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(_abi.lib.vsl_loss_forward_heads(ctypes.byref(desc), heads, n_heads, stream))
         ctx.desc, ctx.heads, ctx.ws, ctx.keep = desc, heads, ws, keep
         ctx.shape = (B, H, W, S, n_heads)
+        ctx.live = [not f for f in cfg["forward_only"]]
         ctx.mark_non_differentiable(ident)
         return losses, ident
 
     @staticmethod
     def backward(ctx, g_losses, _g_ident):
         B, H, W, S, n_heads = ctx.shape
-        dev = ctx.ws[0].device
+        dev = ctx.ws.device
         need = ctx.needs_input_grad  # (cfg, n_heads, disps..., poses...)
-        g_losses = g_losses.contiguous().float()
-        live = [not (ctx.heads[h].flags & _abi.HEAD_NO_GRAD) for h in range(n_heads)]
-        grad_disp = [torch.empty(B, 1, H, W, dtype=torch.float32, device=dev) if (need[2 + h] and live[h]) else None
-                     for h in range(n_heads)]
-        want_T = [need[2 + n_heads + s] for s in range(S)]
-        grad_T = torch.empty(n_heads, S, B, 4, 4, dtype=torch.float32, device=dev) if any(want_T) else None
+        if g_losses.dtype != torch.float32 or not g_losses.is_contiguous():
+            g_losses = g_losses.contiguous().float()
+        live = ctx.live
+        want_d = [bool(need[2 + h]) and live[h] for h in range(n_heads)]
+        want_T = [bool(need[2 + n_heads + s]) for s in range(S)]
+        idx = [h for h in range(n_heads) if live[h]]
+        # one tensor for the disparity gradients of all heads, one for the pose gradients (head-major)
+        grad_disp = torch.empty(n_heads, B, 1, H, W, dtype=torch.float32, device=dev) if any(want_d) else None
+        grad_T = torch.empty(n_heads, S, B, 4, 4, dtype=torch.float32, device=dev) if (any(want_T) and idx) else None
+        gl_ptr = g_losses.data_ptr()
+        gd_ptr = grad_disp.data_ptr() if grad_disp is not None else 0
+        gt_ptr = grad_T.data_ptr() if grad_T is not None else 0
         for h in range(n_heads):
             hd = ctx.heads[h]
-            hd.grad_losses = g_losses[h].data_ptr()
-            hd.grad_disp = grad_disp[h].data_ptr() if grad_disp[h] is not None else None
+            hd.grad_losses = gl_ptr + 4 * _abi.LOSS_SLOTS * h
+            hd.grad_disp = gd_ptr + 4 * B * H * W * h if want_d[h] else None
             for s in range(S):
-                hd.grad_T[s] = grad_T[h, s].data_ptr() if (want_T[s] and live[h]) else None
+                hd.grad_T[s] = gt_ptr + 64 * B * (h * S + s) if (grad_T is not None and want_T[s] and live[h]) else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         _abi.check(_abi.lib.vsl_loss_backward_heads(ctypes.byref(ctx.desc), ctx.heads, n_heads, stream))
-        # every head with gradients differentiates the same pose matrices: their gradients add up
-        idx = [h for h in range(n_heads) if live[h]]
-        gT = [grad_T[idx, s].sum(0) if (want_T[s] and idx) else None for s in range(S)]
-        return (None, None) + tuple(grad_disp) + tuple(gT)
+        # every head with gradients differentiates the same pose matrices: their gradients add up (one reduction
+        # over the head axis for all sources)
+        gT = [None] * S
+        if grad_T is not None:
+            if all(want_T):
+                tot = grad_T.sum(0) if len(idx) == n_heads else grad_T[idx].sum(0)
+                gT = list(tot.unbind(0))
+            else:
+                gT = [grad_T[idx, s].sum(0) if want_T[s] else None for s in range(S)]
+        return (None, None) + tuple(grad_disp[h] if want_d[h] else None for h in range(n_heads)) + tuple(gT)
 
 
 def fused_view_synthesis_loss_heads(disps: Sequence[torch.Tensor], target: torch.Tensor, sources: Sequence[torch.Tensor],

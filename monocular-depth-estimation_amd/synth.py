@@ -104,9 +104,36 @@ def _rodrigues(axisangle: np.ndarray, translation: np.ndarray) -> np.ndarray:
     return M
 
 
+def smooth_disp(batch: int, height: int, width: int, seed: int = 0, head: int = 0, n_patches: int = 6) -> torch.Tensor:
+    """[B,1,H,W] float32 disparity of a street-like scene: a ground plane below a horizon (disparity grows
+    linearly with the image row, as a plane seen by a pinhole camera does), a far background above it and a few
+    fronto-parallel rectangles of constant disparity standing on the ground.  Piecewise smooth, the opposite extreme of
+    make_batch's blurred noise: neighbouring pixels sample the source frames next to each other.  Heads differ by
+    a few per cent in the ground slope and the patch disparities."""
+    ys = np.arange(height, dtype=np.float64)[:, None] / float(height - 1)
+    out = np.empty((batch, 1, height, width), dtype=np.float64)
+    u = uniform(seed + 5, (batch, n_patches, 5), stream=60)
+    wob = uniform(seed + 5, (batch, 2 + n_patches), stream=61 + head)
+    for b in range(batch):
+        horizon = 0.35 + 0.1 * u[b, 0, 0]
+        slope = (0.75 + 0.1 * wob[b, 0]) / (1.0 - horizon)
+        d = np.where(ys > horizon, 0.06 + slope * (ys - horizon), 0.06) + np.zeros((1, width))
+        for p in range(n_patches):
+            cx, foot, w_rel, h_rel, _ = u[b, p]
+            foot_y = horizon + (1.0 - horizon) * (0.15 + 0.8 * foot)        # where the patch touches the ground
+            dp = (0.06 + slope * (foot_y - horizon)) * (1.0 + 0.03 * (wob[b, 2 + p] - 0.5))
+            x0 = int(cx * width * 0.9)
+            x1 = min(width, x0 + 8 + int(w_rel * width * 0.15))
+            y1 = int(foot_y * (height - 1))
+            y0 = max(0, y1 - 4 - int(h_rel * height * 0.4))
+            d[y0:y1 + 1, x0:x1] = np.maximum(d[y0:y1 + 1, x0:x1], dp)        # nearer surfaces occlude
+        out[b, 0] = np.clip(d, 0.05, 0.95)
+    return torch.from_numpy(out.astype(np.float32)).contiguous()
+
+
 def make_batch(batch: int, height: int, width: int, frame_ids: Sequence = (0, -1, 1),
                seed: int = 0, pose_sigma: float = 0.01, n_heads: int = 1,
-               image_dtype: torch.dtype = torch.float32, blur: int = 5) -> Dict:
+               image_dtype: torch.dtype = torch.float32, blur: int = 5, disp: str = "noise") -> Dict:
     """Synthetic inputs for one step.
 
     Returns a dict with
@@ -115,12 +142,18 @@ def make_batch(batch: int, height: int, width: int, frame_ids: Sequence = (0, -1
       "K", "inv_K"   [B,4,4]    float32
       ("cam_T_cam", f) [B,4,4]  float32 for temporal sources, "stereo_T" for 's'
       "noise"        [B,S,H,W]  float32 N(0,1) (tie-break noise of Trainer.py:589)
+    ``disp``: "noise" = box-blurred uniform noise (the benchmark's default), "smooth" = smooth_disp().
     """
     out: Dict = {}
     for i, f in enumerate(frame_ids):
         img = box_blur(uniform(seed, (batch, 3, height, width), stream=10 + i), blur)
         out[("image", f)] = torch.from_numpy(img.astype(np.float32)).to(image_dtype).contiguous()
+    if disp not in ("noise", "smooth"):
+        raise ValueError("disp is 'noise' or 'smooth'")
     for h in range(n_heads):
+        if disp == "smooth":
+            out[("disp", h)] = smooth_disp(batch, height, width, seed, h)
+            continue
         d = box_blur(uniform(seed + 1, (batch, 1, height, width), stream=40 + h), blur)
         d = 0.05 + 0.9 * d
         out[("disp", h)] = torch.from_numpy(d.astype(np.float32)).contiguous()
