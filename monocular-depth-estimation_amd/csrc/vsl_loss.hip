@@ -127,6 +127,14 @@ struct HeadArgs {
   TileDiv td;
 };
 
+// timing probe only (-DVSL_PROBE_NOBAR, results wrong): the tile program without its barriers, i.e. the cost of the
+// phase coupling between the four waves of a workgroup
+#ifdef VSL_PROBE_NOBAR
+#define VSL_TILE_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define VSL_TILE_SYNC() __syncthreads()
+#endif
+
 template <int S, bool AVG, bool OUT>
 __global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG)), (fused_blocks_per_cu<S, AVG>()))
 void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
@@ -162,20 +170,20 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
   VSL_STAMP(1);
   F::phase1(kp, hv, bk, tid, lds, st);
   VSL_STAMP(2);
-  __syncthreads();
+  VSL_TILE_SYNC();
   VSL_STAMP(3);
   F::phase2(kp, hv, bk, tid, lds, st);
   VSL_STAMP(4);
-  __syncthreads();
+  VSL_TILE_SYNC();
   VSL_STAMP(5);
   F::phase3(kp, hv, bk, tid, lds, st);
   VSL_STAMP(6);
-  __syncthreads();
+  VSL_TILE_SYNC();
   VSL_STAMP(7);
   F::phase4_store(tid, lds, st);
-  __syncthreads();
+  VSL_TILE_SYNC();
   F::phase4_sum_a(tid, lds);
-  __syncthreads();
+  VSL_TILE_SYNC();
   F::phase4_sum_b(hv, block_linear, tid, lds);
   VSL_STAMP(8);
 #ifdef VSL_STAMPS

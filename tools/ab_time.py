@@ -9,7 +9,7 @@ for rnd in range(3):
         env = dict(os.environ)
         if l != "default":
             env["VSL_LIBRARY"] = os.path.join(ROOT, "tools", l)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "10", "--no-cpu-baseline"],
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-e2e", "--no-extras"],
                              env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         d = json.loads(out)
         res[l].append((d["roofline"]["kernel_ms"] * 1e3, d["ms_per_step"] * 1e3))
