@@ -225,6 +225,23 @@ int vsl_loss_forward_static(const vsl_loss_desc* desc, float* losses, float* ide
 int vsl_loss_backward_heads(const vsl_loss_desc* desc, const vsl_head* heads, int n_heads, void* stream);
 
 /*
+ * The same two calls with the caller's structure sizes spelled out: desc_bytes = sizeof(vsl_loss_desc) and
+ * head_bytes = sizeof(vsl_head) as the CALLER was compiled.  vsl_head has grown between library versions (128 ->
+ * 200 bytes with the optional outputs); a binary built against another layout gets VSL_ERR_INVALID_ARGUMENT here
+ * instead of having the bytes of its table read as other fields (and stored through).  Callers that may meet a
+ * library other than the one they were built with should use these, through the macros below; such a caller must
+ * be recompiled against the new header, relinking is not enough.
+ */
+int vsl_loss_forward_heads_checked(const vsl_loss_desc* desc, size_t desc_bytes, const vsl_head* heads, size_t head_bytes,
+                                   int n_heads, void* stream);
+int vsl_loss_backward_heads_checked(const vsl_loss_desc* desc, size_t desc_bytes, const vsl_head* heads, size_t head_bytes,
+                                    int n_heads, void* stream);
+#define VSL_LOSS_FORWARD_HEADS(desc, heads, n_heads, stream) \
+  vsl_loss_forward_heads_checked((desc), sizeof(vsl_loss_desc), (heads), sizeof(vsl_head), (n_heads), (stream))
+#define VSL_LOSS_BACKWARD_HEADS(desc, heads, n_heads, stream) \
+  vsl_loss_backward_heads_checked((desc), sizeof(vsl_loss_desc), (heads), sizeof(vsl_head), (n_heads), (stream))
+
+/*
  * Pose preparation in front of the loss: transformation_from_parameters (Python/layers.py:28-45, with
  * rot_from_axisangle :64-103 and get_translation_matrix :48-61) for every source frame of a batch in one
  * launch, as Trainer.predict_pose calls it (Python/Trainer.py:393 inverted for negative frame ids in
@@ -360,7 +377,7 @@ size_t vsl_depth_metrics_workspace_bytes(const vsl_depth_metrics_desc* desc);
 int vsl_depth_metrics(const vsl_depth_metrics_desc* desc, float* metrics, void* workspace, size_t workspace_bytes,
                       void* stream);
 
-/* Library version, e.g. 200 for 0.2.0 (the first with the 200-byte vsl_head). */
+/* Library version, e.g. 200 for 0.2.0 (the first with the 200-byte vsl_head), 210 for 0.2.1 (the *_checked calls). */
 int vsl_version(void);
 
 #ifdef __cplusplus

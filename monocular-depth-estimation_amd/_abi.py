@@ -21,9 +21,10 @@ LOSS_TOTAL, LOSS_PHOTO, LOSS_SMOOTH, LOSS_SCALE0 = 0, 1, 2, 3
 LOSS_SLOTS = 3 + MAX_SCALES
 STATIC_SCRATCH_BYTES = 4 << 20
 
-MIN_VERSION = 200
+MIN_VERSION = 210
 EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", "vsl_identity_min",
-           "vsl_loss_forward_heads", "vsl_loss_backward_heads", "vsl_loss_forward_static",
+           "vsl_loss_forward_heads", "vsl_loss_backward_heads", "vsl_loss_forward_heads_checked",
+           "vsl_loss_backward_heads_checked", "vsl_loss_forward_static",
            "vsl_disp_to_depth_fwd", "vsl_disp_to_depth_bwd", "vsl_backproject_fwd", "vsl_backproject_bwd",
            "vsl_project_fwd", "vsl_project_bwd_workspace_bytes", "vsl_project_bwd",
            "vsl_grid_sample_fwd", "vsl_grid_sample_bwd", "vsl_ssim_fwd", "vsl_ssim_bwd",
@@ -134,6 +135,11 @@ def _load():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(LossDesc), ctypes.POINTER(Head), ctypes.c_int, ctypes.c_void_p]
+    for name in ("vsl_loss_forward_heads_checked", "vsl_loss_backward_heads_checked"):
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.POINTER(LossDesc), ctypes.c_size_t, ctypes.POINTER(Head), ctypes.c_size_t, ctypes.c_int,
+                       ctypes.c_void_p]
     lib.vsl_debug_time_fused.restype = ctypes.c_int
     lib.vsl_debug_time_fused.argtypes = [ctypes.POINTER(LossDesc), ctypes.POINTER(Head), ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]
@@ -207,6 +213,17 @@ def _load():
 
 
 lib = _load()
+
+
+def forward_heads(desc, heads, n_heads, stream) -> int:
+    """vsl_loss_forward_heads with this binding's structure sizes checked against the library's."""
+    return lib.vsl_loss_forward_heads_checked(ctypes.byref(desc), ctypes.sizeof(LossDesc), heads, ctypes.sizeof(Head),
+                                              n_heads, stream)
+
+
+def backward_heads(desc, heads, n_heads, stream) -> int:
+    return lib.vsl_loss_backward_heads_checked(ctypes.byref(desc), ctypes.sizeof(LossDesc), heads, ctypes.sizeof(Head),
+                                               n_heads, stream)
 
 
 def check(rc: int) -> None:

@@ -963,10 +963,27 @@ struct Fused {
         const float txe = xs ? tx.t : 1.0f;
         const float w00 = (1.0f - txe) * (1.0f - ty.t), w01 = txe * (1.0f - ty.t);
         const float w10 = (1.0f - txe) * ty.t, w11 = txe * ty.t;
+#if defined(VSL_PROBE_RGBX)
+        // timing probe only (results wrong): the four taps as four 16-byte loads from a texel-interleaved [H,W,4] copy of
+        // the source instead of six 8-byte loads from three planes.  There is no such copy here: the loads go to the
+        // same image's planes at the interleaved layout's offsets, wrapped into the image's 3 H W floats.
+        struct alignas(16) Texel4 { float v[4]; };
+        const unsigned wrap = 3u * HW - 8u;
+        unsigned q0 = o0 << 2;
+        q0 = q0 >= wrap ? q0 - wrap : q0;
+        unsigned q1 = q0 + (ys ? 4u * (unsigned)W : 0u);
+        q1 = q1 >= wrap ? q1 - wrap : q1;
+        const Texel4 t00 = *reinterpret_cast<const Texel4*>(sp + q0), t01 = *reinterpret_cast<const Texel4*>(sp + q0 + 4);
+        const Texel4 t10 = *reinterpret_cast<const Texel4*>(sp + q1), t11 = *reinterpret_cast<const Texel4*>(sp + q1 + 4);
+#endif
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+#if defined(VSL_PROBE_RGBX)
+          const TexelPair a{t00.v[c], t01.v[c]}, b{t10.v[c], t11.v[c]};
+#else
           const float* pc = sp + (size_t)c * HW;
           const TexelPair a = load_texel_pair_at(pc, o0 << 2), b = load_texel_pair_at(pc, o1 << 2);
+#endif
           const float wv = a.lo * w00 + a.hi * w01 + b.lo * w10 + b.hi * w11;
           lds[OFF_WRP + (s * 3 + c) * P2 + p2] = wv;
           if constexpr (OUT) emit_color(kp, hv, bk, ry, rx, pix, s, c, wv);

@@ -668,7 +668,7 @@ extern "C" {
 
 const char* vsl_last_error_string(void) { return vsl_err::g_err.c_str(); }
 
-int vsl_version(void) { return 200; }  // 0.2.0: vsl_head grew to 200 bytes (optional outputs)
+int vsl_version(void) { return 210; }  // 0.2.0: vsl_head grew to 200 bytes (optional outputs); 0.2.1: *_heads_checked
 
 size_t vsl_loss_workspace_bytes(const vsl_loss_desc* d) {
   if (!d || d->B < 1 || d->H < 1 || d->W < 1) return 0;
@@ -989,6 +989,29 @@ int vsl_loss_forward_heads(const vsl_loss_desc* d, const vsl_head* heads, int n_
 int vsl_loss_backward_heads(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, void* stream_) {
   if (!d) return fail(VSL_ERR_INVALID_ARGUMENT, "desc is NULL");
   return backward_impl(d, heads, n_heads, stream_);
+}
+
+// the caller's idea of the two structures against the library's: a binary compiled against another layout is refused
+// instead of having its table misread (and written through)
+static int check_struct_sizes(size_t desc_bytes, size_t head_bytes) {
+  if (desc_bytes != sizeof(vsl_loss_desc) || head_bytes != sizeof(vsl_head))
+    return fail(VSL_ERR_INVALID_ARGUMENT,
+                "structure sizes differ: caller vsl_loss_desc " + std::to_string(desc_bytes) + " / vsl_head " +
+                    std::to_string(head_bytes) + " bytes, library " + std::to_string(sizeof(vsl_loss_desc)) + " / " +
+                    std::to_string(sizeof(vsl_head)) + " (recompile the caller against this library's vsloss.h)");
+  return VSL_OK;
+}
+
+int vsl_loss_forward_heads_checked(const vsl_loss_desc* d, size_t desc_bytes, const vsl_head* heads, size_t head_bytes,
+                                   int n_heads, void* stream_) {
+  if (int rc = check_struct_sizes(desc_bytes, head_bytes)) return rc;
+  return vsl_loss_forward_heads(d, heads, n_heads, stream_);
+}
+
+int vsl_loss_backward_heads_checked(const vsl_loss_desc* d, size_t desc_bytes, const vsl_head* heads, size_t head_bytes,
+                                    int n_heads, void* stream_) {
+  if (int rc = check_struct_sizes(desc_bytes, head_bytes)) return rc;
+  return vsl_loss_backward_heads(d, heads, n_heads, stream_);
 }
 
 // diagnostic / benchmarking: average duration in ms of the fused tile kernel alone over `reps` forward

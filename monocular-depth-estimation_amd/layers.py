@@ -444,6 +444,9 @@ class _WarpMulti(torch.autograd.Function):
         ctx.save_for_backward(disp, K, inv_K, T, *feats)
         ctx.desc = d
         ctx.mark_non_differentiable(sample)
+        # an output nobody differentiates reaches backward as None, not as a tensor of zeros: vsl_warp_multi_bwd then
+        # skips that tensor's gather and scatter altogether (a NULL entry of its g_out table)
+        ctx.set_materialize_grads(False)
         return (sample,) + tuple(outs)
 
     @staticmethod

@@ -107,7 +107,7 @@ class _FusedLossFn(torch.autograd.Function):
             head.depth = depth.data_ptr()
             for s in range(S):
                 head.sample[s], head.color[s] = sample[s].data_ptr(), color[s].data_ptr()
-            _abi.check(_abi.lib.vsl_loss_forward_heads(ctypes.byref(desc), ctypes.byref(head), 1, stream))
+            _abi.check(_abi.forward_heads(desc, ctypes.byref(head), 1, stream))
             extra = (depth, sample, color)
         else:
             _abi.check(_abi.lib.vsl_loss_forward(ctypes.byref(desc), ws.data_ptr(), nbytes, losses.data_ptr(),
@@ -243,7 +243,7 @@ class _FusedHeadsFn(torch.autograd.Function):
             hd.losses = loss_ptr + 4 * _abi.LOSS_SLOTS * h
             hd.identity_selection = ident_ptr + 4 * B * H * W * h if automask else None
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _abi.check(_abi.lib.vsl_loss_forward_heads(ctypes.byref(desc), heads, n_heads, stream))
+        _abi.check(_abi.forward_heads(desc, heads, n_heads, stream))
         ctx.desc, ctx.heads, ctx.ws, ctx.keep = desc, heads, ws, keep
         ctx.shape = (B, H, W, S, n_heads)
         ctx.live = [not f for f in cfg["forward_only"]]
@@ -274,7 +274,7 @@ class _FusedHeadsFn(torch.autograd.Function):
             for s in range(S):
                 hd.grad_T[s] = gt_ptr + 64 * B * (h * S + s) if (grad_T is not None and want_T[s] and live[h]) else None
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _abi.check(_abi.lib.vsl_loss_backward_heads(ctypes.byref(ctx.desc), ctx.heads, n_heads, stream))
+        _abi.check(_abi.backward_heads(ctx.desc, ctx.heads, n_heads, stream))
         # every head with gradients differentiates the same pose matrices: their gradients add up (one reduction
         # over the head axis for all sources)
         gT = [None] * S

@@ -95,19 +95,51 @@ def _to_float32(v):
 class TrainStep:
     def __init__(self, opt, models: Union[Dict[str, torch.nn.Module], torch.nn.Module],
                  optimizer: Optional[torch.optim.Optimizer] = None, num_scales: int = 1, materialise: bool = False,
-                 use_pose_net: bool = True, per_scale: bool = False, autocast_dtype: Optional[torch.dtype] = None):
+                 use_pose_net: Optional[bool] = None, per_scale: bool = False, autocast_dtype: Optional[torch.dtype] = None):
         """``models``: the dict of networks, or a module with NetworkPass's forward (e.g. a NetworkPass wrapped in
         DistributedDataParallel).  ``per_scale``: feed ("disp", s) of every scale to the loss
         (compute_losses_per_scale) instead of the reference's ("disp", 0) everywhere.  ``autocast_dtype``: run the
         networks under torch.autocast with that type (e.g. torch.bfloat16); their outputs are cast back to float32, the
-        loss always computes in float32."""
+        loss always computes in float32.  ``use_pose_net`` (default True) belongs to the NetworkPass this constructor
+        builds from a dict; a ready module carries its own setting, and passing a different one here is an error."""
         self.opt = opt
-        self.net = NetworkPass(opt, models, use_pose_net) if isinstance(models, dict) else models
+        if isinstance(models, dict):
+            self.net = NetworkPass(opt, models, True if use_pose_net is None else use_pose_net)
+        else:
+            self.net = models
+            inner = self.network_pass
+            if use_pose_net is not None and hasattr(inner, "use_pose_net") and bool(inner.use_pose_net) != bool(use_pose_net):
+                raise ValueError("use_pose_net=%s contradicts the module's own setting (%s): set it on the NetworkPass"
+                                 % (use_pose_net, inner.use_pose_net))
         self.optimizer = optimizer
         self.materialise = materialise
         self.per_scale = per_scale
         self.autocast_dtype = autocast_dtype
         self.loss = ViewSynthesisLoss(opt, num_scales=num_scales)
+
+    # what the reference trainer keeps as attributes of its own (Trainer.py:24,31-37), read through to the network module
+    @property
+    def network_pass(self):
+        """The NetworkPass behind ``net`` (unwrapped from DistributedDataParallel's ``.module``)."""
+        return getattr(self.net, "module", self.net)
+
+    @property
+    def models(self):
+        return self.network_pass.models
+
+    @property
+    def use_pose_net(self):
+        return self.network_pass.use_pose_net
+
+    @property
+    def num_pose_frames(self):
+        return self.network_pass.num_pose_frames
+
+    def predict_pose(self, inputs: Dict, features: Dict) -> Dict:
+        """Trainer.predict_pose (Python/Trainer.py:360-416): pose network, then every pose matrix in one launch."""
+        images = {f: inputs[("image_aug", f)] for f in self.opt.frame_ids}
+        aa, tr = self.network_pass.pose_parameters(images, features)
+        return self.loss.pose_outputs(aa, tr)
 
     # ------------------------------------------------------------------ Trainer.py:328-358
     def process_batch(self, inputs: Dict, noise: Optional[torch.Tensor] = None) -> Tuple[Dict, Dict]:

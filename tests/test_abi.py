@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(abi.EXPORTS)
     for name in declared:
         assert hasattr(abi.lib, name), name
-    assert abi.lib.vsl_version() >= 200
+    assert abi.lib.vsl_version() >= 210
 
 
 def test_descriptor_mirror_and_workspace_query():
@@ -53,6 +53,23 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"2^28" in abi.lib.vsl_last_error_string()
     with pytest.raises(abi.VslError):
         abi.check(-1)
+
+
+def test_heads_calls_reject_a_caller_built_against_another_struct_layout():
+    """vsl_head was 128 bytes before it carried the optional outputs: a caller compiled against that header must get an
+    error from the size-checked calls, not have bytes 128..199 of its table read as output pointers."""
+    import mde_amd._abi as abi
+    d = abi.LossDesc()
+    d.B, d.H, d.W, d.S = 1, 8, 8, 1
+    heads = (abi.Head * 1)()
+    for fn in (abi.lib.vsl_loss_forward_heads_checked, abi.lib.vsl_loss_backward_heads_checked):
+        rc = fn(ctypes.byref(d), ctypes.sizeof(abi.LossDesc), heads, 128, 1, None)
+        assert rc == -1 and b"recompile" in abi.lib.vsl_last_error_string()
+        rc = fn(ctypes.byref(d), 200, heads, ctypes.sizeof(abi.Head), 1, None)
+        assert rc == -1 and b"structure sizes differ" in abi.lib.vsl_last_error_string()
+    # with matching sizes the call goes on to the ordinary argument checks (NULL tensors here)
+    rc = abi.forward_heads(d, heads, 1, None)
+    assert rc == -1 and b"structure sizes" not in abi.lib.vsl_last_error_string()
 
 
 def test_inv_num_scales_and_identity_min_limits_without_gpu():

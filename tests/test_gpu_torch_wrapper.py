@@ -49,3 +49,83 @@ def test_libtorch_binding_matches_fixture(name):
         assert rel(poses[i].grad, z["grad_T_%s" % f]) <= 1e-5
     if cfg["automask"]:
         assert np.array_equal(ident.cpu().numpy(), z["identity_selection"])
+
+
+def _case_tensors(name, dev="cuda:0"):
+    cfg, z = load_case(name)
+    srcs = [fid_key(f) for f in cfg["frame_ids"]][1:]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return cfg, z, srcs, t
+
+
+@pytest.mark.gpu
+def test_libtorch_heads_student_and_forward_only_teacher():
+    """Student head (gradients) + teacher head (forward only) in one launch through the C++ binding, on the
+    distillation trainer's fixture (photometric terms x 0.9, Trainer_distilation.py:1232-1234): the student's loss
+    and gradients match the reference, both heads equal the ctypes binding bit for bit, the teacher gets nothing."""
+    from mde_amd.ops import fused_view_synthesis_loss_heads
+    ext = load_ext()
+    cfg, z, srcs, t = _case_tensors("b2_24x80_distil_scale09")
+    images = [t(z["image_%s" % f]) for f in srcs]
+
+    def leaves():
+        student = t(z["disp"]).requires_grad_(True)
+        teacher = (t(z["disp"]) * 0.9 + 0.03).requires_grad_(True)      # another disparity over the same frames
+        poses = [t(z["T_%s" % f]).requires_grad_(True) for f in srcs]
+        return student, teacher, poses
+
+    student, teacher, poses = leaves()
+    out = ext.loss_heads([student, teacher], t(z["image_0"]), images, t(z["K"]), t(z["inv_K"]), poses, t(z["noise"]),
+                         True, 0.9, [False, True], [[1e-3], [1e-3]], [False, False])
+    losses, ident = out[0], out[1]
+    assert losses.shape == (2, 11) and ident.shape[0] == 2
+    (losses[0, 0] + losses[1, 0]).backward()        # the teacher's loss enters the objective but carries no gradient
+    ref = float(z["loss"])
+    assert abs(losses[0, 0].item() - ref) <= 1e-5 * ref
+    rel = lambda a, b: float(np.linalg.norm(a.detach().cpu().numpy().astype(np.float64) - b) / np.linalg.norm(b))
+    assert rel(student.grad, z["grad_disp"]) <= 1e-5
+    for i, f in enumerate(srcs):
+        assert rel(poses[i].grad, z["grad_T_%s" % f]) <= 1e-5
+    assert teacher.grad is None
+    assert np.array_equal(ident[0].cpu().numpy(), z["identity_selection"])
+
+    s2, t2, p2 = leaves()
+    l2, i2 = fused_view_synthesis_loss_heads([s2, t2], t(z["image_0"]), images, t(z["K"]), t(z["inv_K"]), p2, t(z["noise"]),
+                                             automask=True, warp_scale=0.9, scale_weights=[[1e-3], [1e-3]],
+                                             forward_only=[False, True])
+    (l2[0, 0] + l2[1, 0]).backward()
+    assert torch.equal(l2, losses) and torch.equal(i2, ident)
+    assert torch.equal(s2.grad, student.grad)
+    for a, b in zip(p2, poses):
+        assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["b2_24x80_automask", "b2_24x80_stereo"])
+def test_libtorch_heads_materialise_matches_fixture(name):
+    """depth / sampling grid / warped frames (Trainer.py:436,464,467) out of the C++ heads call: grid and depth bit
+    for bit against the reference fixture, warped colours within float32 of its float64 values; the second head (same
+    disparity, asks for nothing) returns no outputs and the same loss."""
+    ext = load_ext()
+    cfg, z, srcs, t = _case_tensors(name)
+    disp = t(z["disp"]).requires_grad_(True)
+    twin = t(z["disp"]).requires_grad_(True)
+    poses = [t(z["T_%s" % f]).requires_grad_(True) for f in srcs]
+    out = ext.loss_heads([disp, twin], t(z["image_0"]), [t(z["image_%s" % f]) for f in srcs], t(z["K"]), t(z["inv_K"]), poses,
+                         t(z["noise"]) if cfg["automask"] else torch.Tensor(), cfg["automask"], 1.0, [False, False],
+                         [[1e-3 / 2 ** s for s in cfg["scales"]]] * 2, [True, False])
+    losses = out[0]
+    depth, sample, color = out[2], out[3], out[4]
+    assert out[5].numel() == 0 and out[6].numel() == 0 and out[7].numel() == 0
+    assert torch.equal(losses[0], losses[1])
+    ref = float(z["loss"])
+    assert abs(losses[0, 0].item() - ref) <= 1e-5 * ref
+    assert np.array_equal(depth.cpu().numpy(), z["depth"])
+    for i, f in enumerate(srcs):
+        assert np.array_equal(sample[i].cpu().numpy(), z["sample_%s" % f])
+        assert np.abs(color[i].cpu().numpy() - z["color_%s" % f]).max() <= 2e-6
+    assert not depth.requires_grad and not color.requires_grad
+    losses[0, 0].backward()
+    rel = lambda a, b: float(np.linalg.norm(a.detach().cpu().numpy().astype(np.float64) - b) / np.linalg.norm(b))
+    assert rel(disp.grad, z["grad_disp"]) <= 1e-5
+    assert twin.grad is None or float(twin.grad.abs().max()) == 0.0      # its loss did not enter the objective

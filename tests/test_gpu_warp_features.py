@@ -253,6 +253,46 @@ def test_colour_and_affinity_in_one_launch_match_fixture_and_separate_calls():
         assert tuple(outputs[("color", g)].shape) == tuple(inputs[("image", g)].shape)
 
 
+def test_warp_multi_bwd_with_a_null_upstream_gradient_entry():
+    """vsl_warp_multi_bwd through the C-ABI with a NULL entry in its g_out table ("this tensor has no upstream
+    gradient"): same disparity and pose gradients, bit for bit, as the call that passes a tensor of zeros there, and the
+    skipped tensor's own gradient comes back as zeros."""
+    import ctypes
+    import mde_amd._abi as abi
+    import mde_amd.synth as synth
+    B, H, W = 2, 24, 80
+    data = synth.make_batch(B, H, W, [0, -1], seed=5)
+    t = {k: v.to(DEV) for k, v in data.items() if torch.is_tensor(v)}
+    feats = [t[("image", -1)], torch.rand(B, 25, H, W, device=DEV)]
+    d = abi.WarpMultiDesc()
+    d.B, d.H, d.W, d.n = B, H, W, 2
+    d.min_depth, d.max_depth, d.eps = 0.1, 100.0, 1e-7
+    for i, f in enumerate(feats):
+        d.C[i], d.feats[i] = f.shape[1], f.data_ptr()
+    d.disp, d.K, d.inv_K, d.T = t[("disp", 0)].data_ptr(), t["K"].data_ptr(), t["inv_K"].data_ptr(), t[("cam_T_cam", -1)].data_ptr()
+    nbytes = abi.lib.vsl_warp_multi_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=DEV)
+    g1 = torch.randn(B, 25, H, W, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(g0):
+        go, gf = (ctypes.c_void_p * abi.MAX_WARP_TENSORS)(), (ctypes.c_void_p * abi.MAX_WARP_TENSORS)()
+        go[0], go[1] = (g0.data_ptr() if g0 is not None else None), g1.data_ptr()
+        gfe = [torch.full_like(feats[0], 7.0), torch.zeros_like(feats[1])]
+        gf[0], gf[1] = gfe[0].data_ptr(), gfe[1].data_ptr()
+        g_disp, g_T = torch.empty(B, 1, H, W, device=DEV), torch.empty(B, 4, 4, device=DEV)
+        abi.check(abi.lib.vsl_warp_multi_bwd(ctypes.byref(d), go, gf, g_disp.data_ptr(), g_T.data_ptr(), ws.data_ptr(),
+                                             ws.numel() * 8, stream))
+        torch.cuda.synchronize()
+        return g_disp, g_T, gfe
+
+    gd_null, gT_null, gf_null = run(None)
+    gd_zero, gT_zero, _ = run(torch.zeros_like(feats[0]))
+    assert torch.equal(gd_null, gd_zero) and torch.equal(gT_null, gT_zero)
+    assert float(gd_null.abs().max()) > 0
+    assert float(gf_null[0].abs().max()) == 0.0 and float(gf_null[1].abs().max()) > 0      # no upstream gradient: zeros
+
+
 def test_affinity_loss_kernel_matches_torch_ops_and_fixture():
     """vsl_affinity_loss_fwd / _bwd against the reference's op sequence (Python/Trainer.py:497-516) on the fixture's
     warped map, target map and pinned torch.rand_like tensor: value and gradient with respect to the prediction."""

@@ -87,3 +87,34 @@ def test_static_scratch_rejects_oversized_shapes():
     out = torch.zeros(abi.LOSS_SLOTS, device=DEV)
     rc = abi.lib.vsl_loss_forward_static(ctypes.byref(d), out.data_ptr(), None, None)
     assert rc == -2 and b"VSL_STATIC_SCRATCH_BYTES" in abi.lib.vsl_last_error_string()
+
+
+def test_static_scratch_forward_inside_a_hip_graph():
+    """The contract that gives the entry point its purpose: it allocates and frees nothing, so it can be captured.
+    One call outside the capture first (the library looks up its scratch array's address once per device), then the
+    call is captured into a HIP graph on a side stream -- a capture fails on any allocating call -- and replayed twice;
+    every replay must reproduce the eager result bit for bit, also after the outputs were overwritten."""
+    import mde_amd._abi as abi
+    import mde_amd.synth as synth
+    B, H, W, fids = 2, 64, 160, [0, -1, 1]
+    data = synth.make_batch(B, H, W, fids, seed=9, n_heads=1)
+    t = {k: v.to(DEV) for k, v in data.items() if torch.is_tensor(v)}
+    d = _desc(abi, t, B, H, W, fids, abi.FLAG_AUTOMASK)
+    losses, sel = torch.zeros(abi.LOSS_SLOTS, device=DEV), torch.full((B, H, W), -1.0, device=DEV)
+    abi.check(abi.lib.vsl_loss_forward_static(ctypes.byref(d), losses.data_ptr(), sel.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    want_l, want_s = losses.clone(), sel.clone()
+    assert want_l[abi.LOSS_TOTAL].item() > 0
+
+    side = torch.cuda.Stream(DEV)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        abi.check(abi.lib.vsl_loss_forward_static(ctypes.byref(d), losses.data_ptr(), sel.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream))
+    for _ in range(2):
+        losses.zero_()
+        sel.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(losses, want_l) and torch.equal(sel, want_s)
