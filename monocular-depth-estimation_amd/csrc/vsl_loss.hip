@@ -165,18 +165,38 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
     o[11] = ((unsigned long long)xcc << 32) | hw;
   }
 #endif
+  // timing probes only (-DVSL_PROBE_SKIP=<bits>, results wrong): 1 = no phase 1, 2 = no phase 2, 4 = no phase 3
+#ifndef VSL_PROBE_SKIP
+#define VSL_PROBE_SKIP 0
+#endif
   VSL_STAMP(0);
   F::phase0(kp, hv, bk, tid, st);
   VSL_STAMP(1);
-  F::phase1(kp, hv, bk, tid, lds, st);
+  if constexpr (!(VSL_PROBE_SKIP & 1)) {
+    F::phase1(kp, hv, bk, tid, lds, st);
+  } else {
+    st.photo = 0.0f;
+    st.live = 0u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int q = 0; q < S; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) st.dp[k][q][c][0] = st.dp[k][q][c][1] = (float)tid;
+  }
   VSL_STAMP(2);
   VSL_TILE_SYNC();
   VSL_STAMP(3);
-  F::phase2(kp, hv, bk, tid, lds, st);
+  if constexpr (!(VSL_PROBE_SKIP & 2)) F::phase2(kp, hv, bk, tid, lds, st);
   VSL_STAMP(4);
   VSL_TILE_SYNC();
   VSL_STAMP(5);
-  F::phase3(kp, hv, bk, tid, lds, st);
+  if constexpr (!(VSL_PROBE_SKIP & 4)) {
+    F::phase3(kp, hv, bk, tid, lds, st);
+  } else {
+#pragma unroll
+    for (int k = 0; k < F::NPART; ++k) st.part[k] = st.photo + st.dp[0][0][0][0] * (float)k;
+  }
   VSL_STAMP(6);
   VSL_TILE_SYNC();
   VSL_STAMP(7);
