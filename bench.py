@@ -512,14 +512,26 @@ def main():
     fused_ms = time_fused(step, reps, stream)
     ranks_seen, rccl = rccl_probe(dev, world)
 
+    def optional(fn):
+        """The blocks beside the contract's keys must not cost the line its headline: on one rank a failure is
+        recorded in place of the block (with several ranks it propagates: the others are inside the same collectives)."""
+        if world > 1:
+            return fn()
+        try:
+            return fn()
+        except Exception as exc:  # noqa: BLE001
+            return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     e2e = None
     if not args.no_e2e:
         # the training step the >= 7x scaling target is about: networks + pose preparation + loss + backward + Adam,
         # ONE DistributedDataParallel wrapper (gradient all-reduce on the process group) when world > 1
-        sys.path.insert(0, os.path.join(ROOT, "examples"))
-        import synthetic_train as ex
-        e2e = ex.run(dev, rank, world, steps=args.e2e_steps, warmup=3, batch=12, height=192, width=640, ddp=world > 1,
-                     host_staged=backend != "nccl")
+        def run_e2e():
+            sys.path.insert(0, os.path.join(ROOT, "examples"))
+            import synthetic_train as ex
+            return ex.run(dev, rank, world, steps=args.e2e_steps, warmup=3, batch=12, height=192, width=640, ddp=world > 1,
+                          host_staged=backend != "nccl")
+        e2e = optional(run_e2e)
 
     if rank == 0:
         frames = B * world * args.steps
@@ -568,13 +580,14 @@ def main():
         if e2e is not None:
             out["e2e"] = e2e
         if world == 1 and headline and not args.no_extras:
-            out["other_configs"] = [short_run("c3", dev, stream, stream_obj), short_run("c5", dev, stream, stream_obj)]
-            out["smooth_disp"] = short_run("c2", dev, stream, stream_obj, disp="smooth")
+            out["other_configs"] = [optional(lambda: short_run("c3", dev, stream, stream_obj)),
+                                    optional(lambda: short_run("c5", dev, stream, stream_obj))]
+            out["smooth_disp"] = optional(lambda: short_run("c2", dev, stream, stream_obj, disp="smooth"))
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(data, B, H, W, fids, frames / wall)
+            out["cpu_baseline"] = optional(lambda: cpu_baseline(data, B, H, W, fids, frames / wall))
             # ratio to the CPU oracle on this box's host cores, same per-rank workload (vs_baseline stays null:
             # the reference publishes no number for this metric)
-            out["vs_cpu_baseline"] = out["cpu_baseline"]["gpu_over_cpu"]
+            out["vs_cpu_baseline"] = out["cpu_baseline"].get("gpu_over_cpu")
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as td
