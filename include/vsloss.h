@@ -267,6 +267,17 @@ int vsl_pose_fwd(const vsl_pose_desc* desc, float* const* T, void* stream);
 int vsl_pose_bwd(const vsl_pose_desc* desc, const float* const* g_T, float* const* g_axisangle,
                  float* const* g_translation, float* g_t_scale, void* stream);
 
+/*
+ * The "posecnn" pose model's preparation (Python/Trainer.py:446-455) in two launches instead of three: the per-image
+ * mean of 1/depth of `disp` [B,1,H,W] (per-chunk partial sums), then ONE launch that finishes the means, scales the
+ * translations with them and builds every pose matrix.  desc->t_scale is ignored; t_scale_out [B] receives the means
+ * (pass it as desc->t_scale to vsl_pose_bwd, whose g_t_scale then goes to vsl_mean_inv_depth_bwd).  Results equal
+ * vsl_mean_inv_depth_fwd followed by vsl_pose_fwd bit for bit.  workspace: vsl_mean_inv_depth_workspace_bytes(B)
+ * bytes, 8-byte aligned.
+ */
+int vsl_pose_fwd_posecnn(const vsl_pose_desc* desc, const float* disp, int H, int W, float min_depth, float max_depth,
+                         float* t_scale_out, float* const* T, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Per-image mean of 1/depth with depth = disp_to_depth(disp)[1] (Python/Trainer.py:451-452):
  * disp [B,1,H,W] -> out [B].  Backward: g_disp [B,1,H,W] = (or +=, if accumulate) g_out[b] * d out[b] / d disp. */
 size_t vsl_mean_inv_depth_workspace_bytes(int B);

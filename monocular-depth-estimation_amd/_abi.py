@@ -29,7 +29,7 @@ EXPORTS = ("vsl_loss_workspace_bytes", "vsl_loss_forward", "vsl_loss_backward", 
            "vsl_project_fwd", "vsl_project_bwd_workspace_bytes", "vsl_project_bwd",
            "vsl_grid_sample_fwd", "vsl_grid_sample_bwd", "vsl_ssim_fwd", "vsl_ssim_bwd",
            "vsl_smooth_workspace_bytes", "vsl_smooth_fwd", "vsl_smooth_bwd",
-           "vsl_pose_fwd", "vsl_pose_bwd", "vsl_depth_metrics_workspace_bytes", "vsl_depth_metrics",
+           "vsl_pose_fwd", "vsl_pose_bwd", "vsl_pose_fwd_posecnn", "vsl_depth_metrics_workspace_bytes", "vsl_depth_metrics",
            "vsl_warp_features_workspace_bytes", "vsl_warp_features_fwd", "vsl_warp_features_bwd",
            "vsl_warp_multi_workspace_bytes", "vsl_warp_multi_fwd", "vsl_warp_multi_bwd",
            "vsl_affinity_loss_workspace_bytes", "vsl_affinity_loss_fwd", "vsl_affinity_loss_bwd",
@@ -173,6 +173,8 @@ def _load():
     PT = ctypes.POINTER(ctypes.c_void_p)
     lib.vsl_pose_fwd.restype = ctypes.c_int
     lib.vsl_pose_fwd.argtypes = [ctypes.POINTER(PoseDesc), PT, P]
+    lib.vsl_pose_fwd_posecnn.restype = ctypes.c_int
+    lib.vsl_pose_fwd_posecnn.argtypes = [ctypes.POINTER(PoseDesc), P, I, I, F, F, P, PT, P, SZ, P]
     lib.vsl_pose_bwd.restype = ctypes.c_int
     lib.vsl_pose_bwd.argtypes = [ctypes.POINTER(PoseDesc), PT, PT, PT, P, P]
     lib.vsl_warp_features_workspace_bytes.restype = ctypes.c_size_t

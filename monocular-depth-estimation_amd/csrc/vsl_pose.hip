@@ -31,6 +31,11 @@ struct PoseArgs {
   const float* t_scale;  // [B] or null
   int B, n_src, aa_stride, tr_stride;
   unsigned invert_mask;
+  // posecnn form: the translation scale is the image's mean inverse depth, of which only the per-chunk partial sums
+  // exist yet ([B][kMidChunks] doubles); the pose launch finishes the mean itself and leaves it in t_scale_out
+  const double* mid_partial;
+  float* t_scale_out;
+  int HW;
 };
 
 struct PoseOut {
@@ -75,6 +80,8 @@ __device__ __forceinline__ Rot rotation(const float v[3]) {
   return o;
 }
 
+constexpr int kMidChunks = 32;   // partial sums of the mean inverse depth per image
+
 // one thread per (source, image)
 __global__ void k_pose_fwd(PoseArgs a, PoseOut out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,7 +99,13 @@ __global__ void k_pose_fwd(PoseArgs a, PoseOut out) {
     }
   const float v[3] = {aa[0], aa[1], aa[2]};
   const Rot r = rotation(v);
-  const float sc = a.t_scale ? a.t_scale[b] : 1.0f;
+  float sc = a.t_scale ? a.t_scale[b] : 1.0f;
+  if (a.mid_partial) {  // the same sum, in the same order and rounding, as k_mid_final
+    double m = 0.0;
+    for (int i = 0; i < kMidChunks; ++i) m += a.mid_partial[(size_t)b * kMidChunks + i];
+    sc = (float)(m / (double)a.HW);
+    if (s == 0) a.t_scale_out[b] = sc;
+  }
   float t[3] = {tr[0] * sc, tr[1] * sc, tr[2] * sc};  // Trainer.py:455
   float M[3][4];
   if ((a.invert_mask >> s) & 1u) {
@@ -187,7 +200,6 @@ __global__ void k_pose_bwd(PoseArgs a, PoseGrad g) {
 // ---------------------------------------------------------------------------
 // mean inverse depth per image (Trainer.py:451-452): mean over the image of 1 / depth, depth = 1 / (a + c disp)
 // ---------------------------------------------------------------------------
-constexpr int kMidChunks = 32;   // partial sums per image
 constexpr int kMidThreads = 256;
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
@@ -311,6 +323,33 @@ int vsl_mean_inv_depth_fwd(const float* disp, float* out, void* workspace, size_
                      H * W, a, c);
   hipLaunchKernelGGL(k_mid_final, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, out, B,
                      H * W);
+  return launch_status();
+}
+
+int vsl_pose_fwd_posecnn(const vsl_pose_desc* d, const float* disp, int H, int W, float min_depth, float max_depth,
+                         float* t_scale_out, float* const* T, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_pose(d)) return rc;
+  if (!T || !disp || !t_scale_out || !workspace) return fail(VSL_ERR_INVALID_ARGUMENT, "pose (posecnn): null pointer");
+  if (d->B > 65535 || H < 1 || W < 1 || (long long)H * W >= (1LL << 28))
+    return fail(VSL_ERR_INVALID_ARGUMENT, "pose (posecnn): shape out of range");
+  if (!(min_depth > 0.0f) || !(max_depth > min_depth)) return fail(VSL_ERR_INVALID_ARGUMENT, "pose (posecnn): depth range");
+  if (workspace_bytes < vsl_mean_inv_depth_workspace_bytes(d->B)) return fail(VSL_ERR_WORKSPACE_TOO_SMALL, "pose (posecnn): workspace");
+  if ((uintptr_t)workspace % 8) return fail(VSL_ERR_INVALID_ARGUMENT, "pose (posecnn): workspace must be 8-byte aligned");
+  PoseOut o{};
+  for (int s = 0; s < d->n_src; ++s) {
+    if (!T[s]) return fail(VSL_ERR_INVALID_ARGUMENT, "pose: null output pointer");
+    o.T[s] = T[s];
+  }
+  const float a = 1.0f / max_depth, c = 1.0f / min_depth - 1.0f / max_depth;
+  hipLaunchKernelGGL(k_mid_partial, dim3(kMidChunks, d->B), dim3(kMidThreads), 0, (hipStream_t)stream, disp, (double*)workspace,
+                     H * W, a, c);
+  PoseArgs pa = pose_args(d);
+  pa.t_scale = nullptr;
+  pa.mid_partial = (const double*)workspace;
+  pa.t_scale_out = t_scale_out;
+  pa.HW = H * W;
+  const int n = d->B * d->n_src;
+  hipLaunchKernelGGL(k_pose_fwd, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, pa, o);
   return launch_status();
 }
 

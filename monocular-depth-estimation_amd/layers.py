@@ -318,9 +318,77 @@ class _Poses(torch.autograd.Function):
         return (None, g_sc) + tuple(grads)
 
 
-def poses_from_parameters(axisangles, translations, inverts=None, t_scale=None):
+class _PosesPoseCnn(torch.autograd.Function):
+    """The "posecnn" pose model's preparation (Trainer.py:446-455): mean inverse depth of the disparity, scaled
+    translations and all pose matrices in two launches (vsl_pose_fwd_posecnn); the backward chains vsl_pose_bwd and
+    vsl_mean_inv_depth_bwd, so the gradient reaches the pose parameters and the disparity."""
+
+    @staticmethod
+    def forward(ctx, inverts, min_depth, max_depth, disp, *params):
+        n = len(params) // 2
+        aa = [_rows3(params[2 * s], "axisangle") for s in range(n)]
+        tr = [_rows3(params[2 * s + 1], "translation") for s in range(n)]
+        disp = _prep(disp, "disp")
+        if disp.dim() != 4 or disp.shape[1] != 1:
+            raise ValueError("disp must be [B,1,H,W]")
+        B, _, H, W = disp.shape
+        if any(x.shape[0] != B for x in aa + tr):
+            raise ValueError("all pose parameters must have the disparity's batch size")
+
+        def common_stride(rows):
+            st = {3 if B == 1 else r.stride(0) for r in rows}
+            if len(st) > 1:
+                return [r.contiguous() for r in rows], 3
+            return rows, st.pop()
+
+        aa, aa_stride = common_stride(aa)
+        tr, tr_stride = common_stride(tr)
+        d = _abi.PoseDesc()
+        d.B, d.n_src, d.aa_stride, d.tr_stride = B, n, aa_stride, tr_stride
+        d.invert_mask = sum(1 << s for s in range(n) if inverts[s])
+        for s in range(n):
+            d.axisangle[s], d.translation[s] = aa[s].data_ptr(), tr[s].data_ptr()
+        out = [torch.empty(B, 4, 4, dtype=torch.float32, device=disp.device) for _ in range(n)]
+        tab = (ctypes.c_void_p * _abi.MAX_SOURCES)(*[o.data_ptr() for o in out])
+        scale = torch.empty(B, dtype=torch.float32, device=disp.device)
+        nbytes = _lib.vsl_mean_inv_depth_workspace_bytes(B)
+        ws = torch.empty(nbytes // 8, dtype=torch.float64, device=disp.device)
+        _abi.check(_lib.vsl_pose_fwd_posecnn(ctypes.byref(d), disp.data_ptr(), H, W, float(min_depth), float(max_depth),
+                                             scale.data_ptr(), tab, ws.data_ptr(), nbytes, _stream(disp)))
+        d.t_scale = scale.data_ptr()       # what vsl_pose_bwd reads
+        ctx.desc, ctx.keep, ctx.n = d, (aa, tr, scale, disp), n
+        ctx.shapes = [p.shape for p in params]
+        ctx.rng = (float(min_depth), float(max_depth))
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *g_T):
+        d, n = ctx.desc, ctx.n
+        aa, tr, scale, disp = ctx.keep
+        B, dev = d.B, disp.device
+        g = [(x if x is not None else torch.zeros(B, 4, 4, device=dev)).float().contiguous() for x in g_T]
+        g_aa = [torch.empty(B, 3, device=dev) for _ in range(n)]
+        g_tr = [torch.empty(B, 3, device=dev) for _ in range(n)]
+        g_sc = torch.empty(B, device=dev)
+        tab = lambda ts: (ctypes.c_void_p * _abi.MAX_SOURCES)(*[t.data_ptr() for t in ts])
+        _abi.check(_lib.vsl_pose_bwd(ctypes.byref(d), tab(g), tab(g_aa), tab(g_tr), g_sc.data_ptr(), _stream(disp)))
+        g_disp = None
+        if ctx.needs_input_grad[3]:
+            g_disp = torch.empty_like(disp)
+            _abi.check(_lib.vsl_mean_inv_depth_bwd(disp.data_ptr(), g_sc.data_ptr(), g_disp.data_ptr(), 0, B, disp.shape[2],
+                                                   disp.shape[3], ctx.rng[0], ctx.rng[1], _stream(disp)))
+        grads = []
+        for s in range(n):
+            grads += [g_aa[s].reshape(ctx.shapes[2 * s]), g_tr[s].reshape(ctx.shapes[2 * s + 1])]
+        return (None, None, None, g_disp) + tuple(grads)
+
+
+def poses_from_parameters(axisangles, translations, inverts=None, t_scale=None, posecnn_disp=None, depth_range=(0.1, 100.0)):
     """``[transformation_from_parameters(a, t, inv) for a, t, inv in zip(...)]`` (Trainer.py:393,414) in one
-    launch; ``t_scale`` [B] multiplies every translation first (the mean inverse depth of Trainer.py:455)."""
+    launch; ``t_scale`` [B] multiplies every translation first (the mean inverse depth of Trainer.py:455).
+    ``posecnn_disp`` [B,1,H,W] instead of ``t_scale``: that factor is the mean of 1/depth of this disparity
+    (``depth_range`` = (min_depth, max_depth)), finished inside the pose launch itself -- two launches for
+    Trainer.py:446-455 where mean_inverse_depth() + poses_from_parameters(t_scale=...) take three; same values."""
     n = len(axisangles)
     if n < 1 or n > _abi.MAX_SOURCES or len(translations) != n:
         raise ValueError("1..4 (axisangle, translation) pairs")
@@ -330,6 +398,10 @@ def poses_from_parameters(axisangles, translations, inverts=None, t_scale=None):
     params = []
     for a, t in zip(axisangles, translations):
         params += [a, t]
+    if posecnn_disp is not None:
+        if t_scale is not None:
+            raise ValueError("give t_scale or posecnn_disp, not both")
+        return list(_PosesPoseCnn.apply(inverts, depth_range[0], depth_range[1], posecnn_disp, *params))
     return list(_Poses.apply(inverts, t_scale, *params))
 
 

@@ -58,16 +58,17 @@ class ViewSynthesisLoss:
     def _poses(self, inputs, outputs, disp):
         """The pose matrix of every source as the warp uses it.  With the "posecnn" pose model the reference
         rebuilds it from the parameters, the translation multiplied by the image's mean inverse depth
-        (Trainer.py:446-455): one reduction and one pose launch here, differentiable down to disp."""
+        (Trainer.py:446-455): one reduction launch and one pose launch here (the pose launch finishes the mean itself),
+        differentiable down to disp."""
         srcs = self._sources()
         if getattr(self.opt, "pose_model_type", "shared") != "posecnn":
             return [self._pose(inputs, outputs, f) for f in srcs]
         if "s" in srcs:
             raise ValueError("pose_model_type='posecnn' has no stereo branch in the reference (Trainer.py:446-455)")
-        scale = mean_inverse_depth(disp, self.opt.min_depth, self.opt.max_depth)
         return poses_from_parameters([outputs[("axisangle", f)][:, 0] for f in srcs],
                                      [outputs[("translation", f)][:, 0] for f in srcs],
-                                     [f < 0 for f in srcs], t_scale=scale)
+                                     [f < 0 for f in srcs], posecnn_disp=disp,
+                                     depth_range=(self.opt.min_depth, self.opt.max_depth))
 
     # ------------------------------------------------------------------ Trainer.py:388-393,408-414
     def pose_outputs(self, axisangle, translation) -> Dict:

@@ -222,3 +222,32 @@ def test_pose_argument_errors():
         L.poses_from_parameters([a], [torch.zeros(3, 1, 3, device=DEV)])
     with pytest.raises(ValueError):
         L.poses_from_parameters([a], [a], t_scale=torch.ones(5, device=DEV))
+
+
+def test_posecnn_preparation_in_two_launches_equals_the_three_launch_chain():
+    """poses_from_parameters(posecnn_disp=...) -- the mean inverse depth finished inside the pose launch
+    (vsl_pose_fwd_posecnn) -- against mean_inverse_depth() followed by poses_from_parameters(t_scale=...): the same
+    pose matrices and the same gradients of the pose parameters and the disparity, bit for bit."""
+    import mde_amd.layers as L
+    z = load("b2_24x80_posecnn")
+    B = z["disp"].shape[0]
+    g = [torch.randn(B, 4, 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7 + i)) for i in range(2)]
+
+    def run(two_launch):
+        disp = torch.from_numpy(z["disp"]).to(DEV).requires_grad_(True)
+        aa = [torch.from_numpy(z["axisangle_%d" % f]).to(DEV).requires_grad_(True) for f in (-1, 1)]
+        tr = [torch.from_numpy(z["translation_%d" % f]).to(DEV).requires_grad_(True) for f in (-1, 1)]
+        a_list, t_list, inv = [a[:, 0] for a in aa], [t[:, 0] for t in tr], [True, False]
+        if two_launch:
+            Ts = L.poses_from_parameters(a_list, t_list, inv, posecnn_disp=disp, depth_range=(0.1, 100.0))
+        else:
+            Ts = L.poses_from_parameters(a_list, t_list, inv, t_scale=L.mean_inverse_depth(disp, 0.1, 100.0))
+        sum((T * w).sum() for T, w in zip(Ts, g)).backward()
+        return [T.detach() for T in Ts], disp.grad, torch.stack([a.grad for a in aa]), torch.stack([t.grad for t in tr])
+
+    T2, gd2, ga2, gt2 = run(True)
+    T3, gd3, ga3, gt3 = run(False)
+    for a, b in zip(T2, T3):
+        assert torch.equal(a, b)
+    assert torch.equal(gd2, gd3) and torch.equal(ga2, ga3) and torch.equal(gt2, gt3)
+    assert float(gd2.abs().max()) > 0 and float(gt2.abs().max()) > 0
