@@ -373,27 +373,34 @@ def launch_ranks(n):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import tempfile
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rc = rc or 1
-        rc = rc or p.returncode
-    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
-    if rc != 0 or not lines:
-        sys.stdout.write(out0 or "")
-        print("bench.py: a rank failed (exit codes %s)" % [p.returncode for p in procs], file=sys.stderr)
-        return rc or 1
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # wait for all ranks; a rank that dies takes the others with it (they would sit in a collective until its time-out)
+        failed = False
+        while any(p.poll() is None for p in procs):
+            if any(p.returncode not in (None, 0) for p in procs):
+                failed = True
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                break
+            time.sleep(0.2)
+        for p in procs:
+            p.wait()
+        out0.seek(0)
+        text = out0.read()
+    codes = [p.returncode for p in procs]
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if failed or any(codes) or not lines:
+        sys.stdout.write(text)
+        print("bench.py: a rank failed (exit codes %s)" % codes, file=sys.stderr)
+        return next((c for c in codes if c), 1)
     print(lines[-1])
     return 0
 

@@ -43,3 +43,16 @@ def test_bench_refuses_more_ranks_than_gpus():
                           env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert proc.returncode == 2
     assert "GPU(s) visible" in proc.stderr and proc.stdout.strip() == ""
+
+
+def test_bench_reports_a_failing_rank():
+    """Ranks that cannot come up (no GPU behind the device they are pinned to) end the run with a non-zero exit code
+    and a message, quickly -- the parent does not sit waiting for a line that will never come."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                          env=_clean_env(VSL_BENCH_DEVICE="0", VSL_BENCH_BACKEND="gloo"), stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=180)
+    assert proc.returncode != 0
+    assert "a rank failed" in proc.stderr and not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
