@@ -209,7 +209,7 @@ def _cpu_case(O, data, nb, fids, H, W, scales, image_dtype, budget_s, max_runs, 
 
 
 def cpu_baseline(data, B, H, W, fids, gpu_frames_per_s, budget_s=9.0):
-    """Frames/s of the CPU oracle.  Cases: C1 = batch 2 with scales [0] and [0,1,2,3],
+    """Frames/s of the CPU oracle.  Cases: the reference's own CPU-runnable shape, batch 2, with scales [0] and [0,1,2,3],
     float64 images (what the reference's data loader yields) and float32 images; a batch-B pass of the headline
     workload's per-rank shape (4 scales).  Thread count: the better of 16 (this box's CPU share) and every core
     the machine reports, decided on the first case."""

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU-box session of round 3: kernel-trace statistics of the driver-form bench, the two HBM traffic passes, and the
+# GPU-box session: kernel-trace statistics of the driver-form bench, the two HBM traffic passes, and the
 # vector-memory counters for the blurred-noise and the piecewise-smooth disparity.  One rocprofv3 run per pass.
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
