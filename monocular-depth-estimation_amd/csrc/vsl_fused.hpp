@@ -86,6 +86,15 @@ constexpr int fused_tile_h(int S, bool avg) { return (S <= 2 && !avg) ? VSL_TILE
 #endif
 constexpr int fused_tile_w(int S, bool avg) { return (S == 3 && !avg) ? VSL_TILE_W3 : ((S <= 2 && !avg) ? VSL_TILE_W2 : kTileW); }
 constexpr int tile_threads(int th) { return 16 * (th + 4); }
+// Tile height of the forward-only program (halo 1, no coefficient planes: 36 KB of LDS and 62 registers at 28 rows, so
+// four eight-wave workgroups fill a CU's 32 wave slots).  Taller tiles cut its halo work from 1.25 to 1.15 x the output
+// pixels (1280x384 b8, forward-only head: 87.3 -> 82.3 us); the full program loses a factor of two with the same tiles
+// (two of its waves then share a SIMD and are always in the same phase), so the two programs tile the image differently.
+// Two sources, per-pixel minimum only: the other instantiations (more planes, or more registers) keep the full program's height.
+#ifndef VSL_FWD_TILE_H
+#define VSL_FWD_TILE_H 28
+#endif
+constexpr int fwd_tile_h(int S, bool avg) { return (S == 2 && !avg) ? VSL_FWD_TILE_H : fused_tile_h(S, avg); }
 constexpr float kC1 = 0.01f * 0.01f;
 constexpr float kC2 = 0.03f * 0.03f;
 

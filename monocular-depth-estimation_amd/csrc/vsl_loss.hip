@@ -216,8 +216,8 @@ void vsl_fused_kernel(const KParams kp_in, const HeadArgs ha) {
 // forward-only tile kernel (every head of the launch without gradients: validation, teacher heads)
 // --------------------------------------------------------------------------
 template <int S, bool AVG, bool OUT>
-__global__ __launch_bounds__(tile_threads(fused_tile_h(S, AVG))) void vsl_forward_kernel(const KParams kp_in, const HeadArgs ha) {
-  constexpr int TH = fused_tile_h(S, AVG), NT = tile_threads(TH);
+__global__ __launch_bounds__(tile_threads(fwd_tile_h(S, AVG))) void vsl_forward_kernel(const KParams kp_in, const HeadArgs ha) {
+  constexpr int TH = fwd_tile_h(S, AVG), NT = tile_threads(TH);
   constexpr int TW = fused_tile_w(S, AVG);
   using F = Fused<TW, TH, NT, S, AVG, 1, OUT>;
   __shared__ __align__(16) float lds[F::LDS_FLOATS];
@@ -286,6 +286,7 @@ __global__ void vsl_prep_kernel(const KParams kp, const OutArgs oa) {
 // --------------------------------------------------------------------------
 struct FinalizeHead {
   int n_scales;
+  int tiles_per_image;  // of the tile program that wrote this head's records (the forward-only one tiles differently)
   float scale_weight[VSL_MAX_SCALES];
   float photo_w, smooth_w;  // weights of the two terms in the total
   const float* partials;
@@ -298,7 +299,6 @@ struct FinalizeHead {
 
 struct FinalizeParams {
   int B, H, W, S;
-  int tiles_per_image;
   double inv_nx, inv_ny;
   const float* K;
   FinalizeHead head[VSL_MAX_HEADS];
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(1024) void vsl_finalize_kernel(const FinalizeParams
     // to 24 loads are in flight per thread at once: one memory round trip for the 368 tiles of a 640x192 image
     // instead of three (9.2 -> 6.8 us).  The loads are unconditional (past the end: the last record again, not
     // added): as predicated loads the compiler gives each a branch of its own and they run one after the other (12 us).
-    const float* base = fh.partials + (size_t)b * fp.tiles_per_image * kPartStride + v;
-    const int n = fp.tiles_per_image;
+    const float* base = fh.partials + (size_t)b * fh.tiles_per_image * kPartStride + v;
+    const int n = fh.tiles_per_image;
     for (int t = r; t < n; t += 16 * 24) {
       float x[24];
 #pragma unroll
@@ -623,7 +623,7 @@ int launch_fused(const KParams& kp, const HeadArgs& ha, dim3 grid, hipStream_t s
 
 template <int S>
 void launch_forward_s(const KParams& kp, const HeadArgs& ha, bool avg, dim3 grid, hipStream_t stream) {
-  constexpr int NTF = tile_threads(fused_tile_h(S, false)), NTA = tile_threads(fused_tile_h(S, true));
+  constexpr int NTF = tile_threads(fwd_tile_h(S, false)), NTA = tile_threads(fwd_tile_h(S, true));
   const bool out = kp.out_table != nullptr;
   if (avg && out)
     hipLaunchKernelGGL((vsl_forward_kernel<S, true, true>), grid, dim3(NTA), 0, stream, kp, ha);
@@ -725,6 +725,8 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
   if (int rc = check_desc(d)) return rc;
   if (int rc = check_heads(d, heads, n_heads, false)) return rc;
   const Layout L = make_layout(d->B, d->H, d->W, desc_tile_h(d), desc_tile_w(d));
+  // the forward-only program's own tiling (never more tiles than the full program's: the records fit the same region)
+  const Layout LF = make_layout(d->B, d->H, d->W, fwd_tile_h(d->S, (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0), desc_tile_w(d));
   hipStream_t stream = (hipStream_t)stream_;
 
   const bool avg = (d->flags & VSL_FLAG_AVG_REPROJECTION) != 0;
@@ -752,7 +754,6 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
   fp.H = d->H;
   fp.W = d->W;
   fp.S = d->S;
-  fp.tiles_per_image = L.tiles_per_image;
   fp.inv_nx = 1.0 / ((double)d->B * d->H * (d->W - 1));
   fp.inv_ny = 1.0 / ((double)d->B * (d->H - 1) * d->W);
   fp.K = d->K;
@@ -774,6 +775,7 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
     ha.index[h] = h;
     FinalizeHead& fh = fp.head[h];
     fh.n_scales = hd.n_scales;
+    fh.tiles_per_image = ha.want_grad[h] ? L.tiles_per_image : LF.tiles_per_image;
     for (int i = 0; i < VSL_MAX_SCALES; ++i) fh.scale_weight[i] = i < hd.n_scales ? hd.scale_weight[i] : 0.0f;
     fh.photo_w = photo_w;
     fh.smooth_w = smooth_w;
@@ -827,7 +829,8 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
   // through the forward-only one (halo 1, no coefficient planes: about half the time per head): two grids when
   // a call has both kinds.
   HeadArgs hg{}, hf{};
-  hg.td = hf.td = make_tile_div(L);
+  hg.td = make_tile_div(L);
+  hf.td = make_tile_div(LF);
   auto take = [&](HeadArgs& dst, int h) {
     const int i = dst.n_heads++;
     dst.disp[i] = ha.disp[h];
@@ -852,7 +855,7 @@ int forward_impl(const vsl_loss_desc* d, const vsl_head* heads, int n_heads, voi
     }
   }
   if (hf.n_heads && rc == VSL_OK) {
-    const dim3 gf(swizzled_grid(L.blocks * hf.n_heads));
+    const dim3 gf(swizzled_grid(LF.blocks * hf.n_heads));
     switch (d->S) {
       case 1: launch_forward_s<1>(kp, hf, avg, gf, stream); break;
       case 2: launch_forward_s<2>(kp, hf, avg, gf, stream); break;

@@ -35,30 +35,40 @@ template <int S, bool AVG>
 void run_tiles(KParams kp) {
   constexpr int kTH = fused_tile_h(S, AVG), kNT = tile_threads(kTH), kFW = fused_tile_w(S, AVG);
   using F = Fused<kFW, kTH, kNT, S, AVG>;
-  using F1 = Fused<kFW, kTH, kNT, S, AVG, 1>;   // forward-only program
+  // the forward-only program tiles the image with its own tile height
+  constexpr int kTH1 = fwd_tile_h(S, AVG), kNT1 = tile_threads(kTH1);
+  using F1 = Fused<kFW, kTH1, kNT1, S, AVG, 1>;
   if (kp.automask) run_ident<S, AVG>(kp);
-  const bool fwd_only = kp.want_grad == 0;
-  const int tx = (kp.W + kFW - 1) / kFW, ty = (kp.H + kTH - 1) / kTH;
-  std::vector<float> lds(F::LDS_FLOATS > F1::LDS_FLOATS ? F::LDS_FLOATS : F1::LDS_FLOATS);
-  std::vector<ThreadState<S>> st(kNT);
   const HeadView hv = head_view(kp);
+  if (kp.want_grad == 0) {
+    const int tx = (kp.W + kFW - 1) / kFW, ty = (kp.H + kTH1 - 1) / kTH1;
+    std::vector<float> lds(F1::LDS_FLOATS);
+    std::vector<ThreadState<S>> st(kNT1);
+    for (int b = 0; b < kp.B; ++b)
+      for (int by = 0; by < ty; ++by)
+        for (int bx = 0; bx < tx; ++bx) {
+          typename F1::Block bk1{b, bx * kFW, by * kTH1};
+          const int lin = (b * ty + by) * tx + bx;
+          for (auto& v : lds) v = NAN;
+          for (int t = 0; t < kNT1; ++t) F1::phase0(kp, hv, bk1, t, st[t]);
+          for (int t = 0; t < kNT1; ++t) F1::phase1(kp, hv, bk1, t, lds.data(), st[t]);
+          for (int t = 0; t < kNT1; ++t) F1::phase_forward(kp, hv, bk1, t, lds.data(), st[t]);
+          for (int t = 0; t < kNT1; ++t) F1::phase4_store(t, lds.data(), st[t]);
+          for (int t = 0; t < kNT1; ++t) F1::phase4_sum_a(t, lds.data());
+          for (int t = 0; t < kNT1; ++t) F1::phase4_sum_b(hv, lin, t, lds.data());
+        }
+    return;
+  }
+  const int tx = (kp.W + kFW - 1) / kFW, ty = (kp.H + kTH - 1) / kTH;
+  std::vector<float> lds(F::LDS_FLOATS);
+  std::vector<ThreadState<S>> st(kNT);
   for (int b = 0; b < kp.B; ++b)
     for (int by = 0; by < ty; ++by)
       for (int bx = 0; bx < tx; ++bx) {
         typename F::Block bk{b, bx * kFW, by * kTH};
-        typename F1::Block bk1{b, bx * kFW, by * kTH};
         const int lin = (b * ty + by) * tx + bx;
         // poison LDS so that reads of unwritten cells show up as NaNs in the results
         for (auto& v : lds) v = NAN;
-        if (fwd_only) {
-          for (int t = 0; t < kNT; ++t) F1::phase0(kp, hv, bk1, t, st[t]);
-          for (int t = 0; t < kNT; ++t) F1::phase1(kp, hv, bk1, t, lds.data(), st[t]);
-          for (int t = 0; t < kNT; ++t) F1::phase_forward(kp, hv, bk1, t, lds.data(), st[t]);
-          for (int t = 0; t < kNT; ++t) F1::phase4_store(t, lds.data(), st[t]);
-          for (int t = 0; t < kNT; ++t) F1::phase4_sum_a(t, lds.data());
-          for (int t = 0; t < kNT; ++t) F1::phase4_sum_b(hv, lin, t, lds.data());
-          continue;
-        }
         for (int t = 0; t < kNT; ++t) F::phase0(kp, hv, bk, t, st[t]);
         for (int t = 0; t < kNT; ++t) F::phase1(kp, hv, bk, t, lds.data(), st[t]);
         for (int t = 0; t < kNT; ++t) F::phase2(kp, hv, bk, t, lds.data(), st[t]);
@@ -84,4 +94,5 @@ extern "C" int vsl_emu_tiles(const KParams* kp, int avg) {
 extern "C" int vsl_emu_part_stride() { return kPartStride; }
 extern "C" int vsl_emu_tile_w(int S, int avg) { return fused_tile_w(S, avg != 0); }
 extern "C" int vsl_emu_tile_h(int S, int avg) { return fused_tile_h(S, avg != 0); }
+extern "C" int vsl_emu_fwd_tile_h(int S, int avg) { return fwd_tile_h(S, avg != 0); }
 extern "C" int vsl_emu_kparams_size() { return (int)sizeof(KParams); }

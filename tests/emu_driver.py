@@ -61,7 +61,8 @@ def run_emu(disp, target, sources, K, inv_K, Ts, noise, automask=True, avg=False
     sources = [f32(s) for s in sources]
     Ts = [f32(t) for t in Ts]
     noise = f32(noise) if noise is not None else None
-    tw, th, stride = lib.vsl_emu_tile_w(S, int(avg)), lib.vsl_emu_tile_h(S, int(avg)), lib.vsl_emu_part_stride()
+    tw, stride = lib.vsl_emu_tile_w(S, int(avg)), lib.vsl_emu_part_stride()
+    th = lib.vsl_emu_tile_h(S, int(avg)) if want_grad else lib.vsl_emu_fwd_tile_h(S, int(avg))   # the forward-only program's own tiling
     tiles = ((W + tw - 1) // tw) * ((H + th - 1) // th)
     partials = np.full((B * tiles, stride), np.nan, np.float32)
     gphoto = np.full((B, H, W), np.nan, np.float32)
