@@ -204,3 +204,38 @@ def test_runs_on_the_callers_stream():
     a = run(torch.cuda.current_stream(dev))
     b = run(torch.cuda.Stream(device=dev))
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 2), (1, 3, 5), (2, 17, 31), (1, 28, 28), (1, 29, 57), (2, 56, 30), (3, 40, 70)])
+def test_forward_only_program_at_ragged_shapes(shape):
+    """The forward-only tile program tiles the image with 28-row tiles of its own: under torch.no_grad() the losses equal
+    the full program's to float32 summation order (2e-6) and identity_selection exactly, at sizes below, at and just
+    above one tile in either direction; and once against the oracle."""
+    import mde_amd.synth as synth
+    from mde_amd.ops import fused_view_synthesis_loss
+    from oracle import vsl_oracle as O
+    B, H, W = shape
+    fids = [0, -1, 1]
+    data = synth.make_batch(B, H, W, fids, seed=200 + H + W, blur=3)
+    dev = torch.device("cuda:0")
+    args = (data[("image", 0)].to(dev), [data[("image", f)].to(dev) for f in fids[1:]], data["K"].to(dev),
+            data["inv_K"].to(dev))
+    poses = [data[("cam_T_cam", f)].to(dev) for f in fids[1:]]
+    disp = data[("disp", 0)].to(dev)
+    full, ident_full = fused_view_synthesis_loss(disp.clone().requires_grad_(True), *args, poses, data["noise"].to(dev))
+    with torch.no_grad():
+        fwd, ident_fwd = fused_view_synthesis_loss(disp, *args, poses, data["noise"].to(dev))
+    assert torch.allclose(fwd, full.detach(), rtol=2e-6, atol=0), (fwd, full)
+    assert torch.equal(ident_fwd, ident_full)
+    cfg = O.LossConfig(frame_ids=fids, height=H, width=W, automask=True)
+    inputs = {"K": data["K"], "inv_K": data["inv_K"]}
+    for f in fids:
+        inputs[("image", f)] = data[("image", f)].double()
+    outputs = {("disp", 0): data[("disp", 0)].clone()}
+    for f in fids[1:]:
+        outputs[("cam_T_cam", f)] = data[("cam_T_cam", f)].clone()
+    with torch.no_grad():
+        O.view_synthesis(inputs, outputs, cfg)
+        ref = O.compute_losses(inputs, outputs, cfg, data["noise"])
+    assert abs(fwd[0].item() - ref["loss"].item()) <= TOL * abs(ref["loss"].item())
+    assert np.array_equal(ident_fwd.cpu().numpy(), outputs["identity_selection"].numpy())
